@@ -1,0 +1,466 @@
+/* oracle/photon_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement, in plain C, of the photon life cycle of the reference's CUDA kernel
+ * (src/raytracer_kernels.cu:307-569) in the arithmetic the MI355X path computes in:
+ * float32, a counter-based Philox4x32-10 stream keyed on the photon ID (north_star), layered
+ * majorants for null-collision tracking. The HIP kernels in raytracer_amd/csrc must reproduce
+ * the tallies of this file BIT FOR BIT on the same inputs (tests/test_gpu_parity.py); this file
+ * itself is pinned to the reference statistically (tests/test_oracle_photon.py: global fractions
+ * and per-cell z-scores against oracle/cpu_ref.cpp, which in turn is pinned bit-exact to the
+ * compiled reference). The cuRAND streams of the CUDA path cannot be reproduced (cuRAND is not
+ * in /root/reference and not in this image) — RNG-stream parity is unpinned by design, see
+ * DESIGN.md.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
+ *
+ * Every transcendental is built from IEEE-754 correctly rounded operations only (+ - * / sqrt
+ * fma), never libm, so CPU and GPU agree to the bit. The file must be compiled with
+ * -ffp-contract=off; every fused multiply-add is written out as fmaf().
+ *
+ * Reference lines restated (relative to /root/reference/src/):
+ *   launch at TOA ............ raytracer_kernels.cu:180-208   (rt_launch)
+ *   free path ................ raytracer_kernels.cu:165-170, 367
+ *   slab majorants/transition  raytracer_kernels.cu:360-415   (restated as explicit slab state +
+ *                              parametric distance to the next slab face)
+ *   surface / TOA ............ raytracer_kernels.cu:417-434, 455-499
+ *   periodic wrap ............ raytracer_kernels.cu:440-448
+ *   cell index ............... raytracer_kernels.cu:173-178
+ *   collision classifier ..... raytracer_kernels.cu:507-520
+ *   Rayleigh / HG ............ raytracer_kernels.cu:145-162
+ *   scatter frame ............ raytracer_kernels.cu:523-548 with dot() of :70-74
+ *   Lambertian surface ....... raytracer_kernels.cu:463-474
+ *   majorants from the grids . raytracer_3d_io.cu:60-77
+ *   cloud slab bounds ........ raytracer_kernels.cu:263-305  (its four indexing bugs not kept)
+ */
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RT_EPS 1.1920928955078125e-07f /* FLT_EPSILON, raytracer_kernels.cu:24 */
+#define RT_TWO_PI 6.2831854820251465f   /* Float(2.*M_PI) */
+#define RT_MAX_STEPS (1u << 22)
+
+enum { TAG_LAUNCH = 0, TAG_STEP = 1, TAG_SCATTER = 2 };
+
+/* ---------------------------------------------------------------- Philox4x32-10 ---------- */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11). */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round)
+    {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline void draw(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, uint32_t w[4])
+{
+    const uint32_t ctr[4] = {(uint32_t)pid, (uint32_t)(pid >> 32), step, tag};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    oracle_philox4x32_10(ctr, key, w);
+}
+
+/* top 24 bits -> [0,1), every value exactly representable */
+static inline float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
+
+/* ---------------------------------------------------------------- deterministic math ----- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* natural log for positive normal x; mantissa reduced to [sqrt(1/2), sqrt(2)), degree-9
+ * polynomial (Cephes logf coefficients), Horner in fmaf. */
+float oracle_logf(float x)
+{
+    uint32_t ix = f2u(x);
+    ix += 0x3f800000u - 0x3f3504f3u;
+    const int e = (int)(ix >> 23) - 127;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float f = u2f(ix) - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    const float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(fe, 0.693359375f, f + y);
+}
+
+/* sin and cos of 2*pi*u for u in [0,1) on the 2^-24 lattice: exact quadrant reduction, then
+ * degree-7 / degree-8 polynomials on [-pi/4, pi/4] (Cephes sinf/cosf coefficients). */
+void oracle_sincos2pi(float u, float* s_out, float* c_out)
+{
+    const int q = (int)fmaf(u, 4.0f, 0.5f);
+    const float r = u - 0.25f * (float)q;          /* exact */
+    const float x = r * RT_TWO_PI;
+    const float x2 = x * x;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, x2, 8.3321608736e-3f);
+    ps = fmaf(ps, x2, -1.6666654611e-1f);
+    const float s = fmaf(x * x2, ps, x);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, x2, -1.388731625493765e-3f);
+    pc = fmaf(pc, x2, 4.166664568298827e-2f);
+    const float c = fmaf(x2 * x2, pc, fmaf(-0.5f, x2, 1.0f));
+    switch (q & 3)
+    {
+        case 0: *s_out = s;  *c_out = c;  break;
+        case 1: *s_out = c;  *c_out = -s; break;
+        case 2: *s_out = -s; *c_out = -c; break;
+        default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+/* cube root of a positive normal float: bit-shift seed + three Halley steps */
+float oracle_cbrtf(float x)
+{
+    float t = u2f(f2u(x) / 3u + 709958130u);
+    for (int it = 0; it < 3; ++it)
+    {
+        const float t3 = t * t * t;
+        t = t * (fmaf(2.0f, x, t3) / fmaf(2.0f, t3, x));
+    }
+    return t;
+}
+
+/* raytracer_kernels.cu:145-152 with pow(., 1/3) as the cube root above */
+static inline float rayleigh_mu(float r)
+{
+    const float q = fmaf(4.0f, r, -2.0f);
+    const float d = fmaf(q, q, 1.0f);
+    const float u = oracle_cbrtf(-q + sqrtf(d));
+    return u - 1.0f / u;
+}
+
+/* raytracer_kernels.cu:155-162. The reference divides by g; |g| < 1e-3 takes the g -> 0 limit
+ * (isotropic) instead of producing NaN (SURVEY.md §7 "float edge cases"). */
+static inline float henyey_mu(float g, float r)
+{
+    if (fabsf(g) < 1.0e-3f)
+        return fmaf(2.0f, r, -1.0f);
+    const float one_m_g2 = 1.0f - g * g;
+    const float a = one_m_g2 * one_m_g2;
+    const float h = fmaf(2.0f * r, g, 1.0f - g);
+    const float b = (2.0f * g) * (h * h);
+    const float c = -g * 0.5f - 1.0f / (2.0f * g);
+    return -(a / b) - c;
+}
+
+/* raytracer_kernels.cu:165-170 */
+static inline float free_path_tau(float r) { return -oracle_logf((1.0f - r) + RT_EPS); }
+
+/* raytracer_kernels.cu:440-448, fmod restated as floor-multiply so the result is bit-defined */
+static inline float wrap_periodic(float x, float size, float inv_size)
+{
+    const float q = floorf(x * inv_size);
+    x = fmaf(-q, size, x);
+    if (x < 0.0f) x += size;
+    if (x >= size) x -= size;
+    return x;
+}
+
+/* raytracer_kernels.cu:173-178 with s/ds as s*(1/ds), clamped on both sides */
+static inline int cell_of(float s, float inv_ds, int n)
+{
+    int c = (int)(s * inv_ds);
+    if (c > n - 1) c = n - 1;
+    if (c < 0) c = 0;
+    return c;
+}
+
+/* ---------------------------------------------------------------- scene preparation ------ */
+typedef struct
+{
+    int itot, jtot, ktot;
+    float dx, dy, dz;
+    float zenith_rad, azimuth_rad, albedo;
+    int fixed_dot; /* 0 = dot() as the reference writes it (v1.z*v1.z), 1 = v1.z*v2.z */
+} oracle_scene_t;
+
+typedef struct
+{
+    int nslab;          /* 1..3 non-empty horizontal slabs, bottom to top */
+    float zface[4];     /* nslab+1 faces, zface[0] = 0, zface[nslab] = z_size */
+    float kmaj[3];      /* majorant extinction per slab */
+    float inv_kmaj[3];
+    int k_lo, k_hi;     /* cloud levels (asy > 0), -1 if none */
+    float sun[3];       /* direction of the direct beam, raytracer_3d.cu:25-30 */
+} oracle_slabs_t;
+
+/* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
+ * raytracer_3d_io.cu:60-77 (majorants), per slab: max over the slab's levels of gas + cloud. */
+void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const float* k_cloud,
+                        const float* asy, oracle_slabs_t* out)
+{
+    const size_t nlev = (size_t)sc->itot * sc->jtot;
+    int k_lo = -1, k_hi = -1;
+    float* lev_max = (float*)malloc(sizeof(float) * sc->ktot);
+    for (int k = 0; k < sc->ktot; ++k)
+    {
+        float m = 0.0f;
+        int cloudy = 0;
+        for (size_t c = (size_t)k * nlev; c < (size_t)(k + 1) * nlev; ++c)
+        {
+            const float kt = k_gas[c] + k_cloud[c];
+            if (kt > m) m = kt;
+            if (asy[c] > 0.0f) cloudy = 1;
+        }
+        lev_max[k] = m;
+        if (cloudy) { if (k_lo < 0) k_lo = k; k_hi = k; }
+    }
+    out->k_lo = k_lo; out->k_hi = k_hi;
+
+    int lo[3], hi[3], n = 0;
+    if (k_lo < 0) { lo[0] = 0; hi[0] = sc->ktot; n = 1; }
+    else
+    {
+        if (k_lo > 0) { lo[n] = 0; hi[n] = k_lo; ++n; }
+        lo[n] = k_lo; hi[n] = k_hi + 1; ++n;
+        if (k_hi + 1 < sc->ktot) { lo[n] = k_hi + 1; hi[n] = sc->ktot; ++n; }
+    }
+    out->nslab = n;
+    for (int s = 0; s < 3; ++s) { out->kmaj[s] = 0.0f; out->inv_kmaj[s] = 0.0f; }
+    for (int s = 0; s < n; ++s)
+    {
+        float m = 0.0f;
+        for (int k = lo[s]; k < hi[s]; ++k) if (lev_max[k] > m) m = lev_max[k];
+        out->kmaj[s] = m;
+        out->inv_kmaj[s] = 1.0f / m;
+        out->zface[s] = (float)lo[s] * sc->dz;
+    }
+    out->zface[n] = (float)sc->ktot * sc->dz;
+    /* raytracer_3d.cu:25-30: angles are floats, cosines in float. Host libm is fine here: the
+     * product computes the same three numbers on the host and hands them to the kernel, so they
+     * are inputs of the traced path, not results of it. */
+    out->sun[0] = -sinf(sc->zenith_rad) * cosf(sc->azimuth_rad);
+    out->sun[1] = -sinf(sc->zenith_rad) * sinf(sc->azimuth_rad);
+    out->sun[2] = -cosf(sc->zenith_rad);
+    for (int s = n + 1; s < 4; ++s) out->zface[s] = out->zface[n];
+    free(lev_max);
+}
+
+/* ---------------------------------------------------------------- the photon life cycle -- */
+enum { EV_STEP = 0, EV_COLL, EV_REAL, EV_SCAT, EV_CSCAT, EV_SFC, EV_TOA, EV_ABS, EV_TRANS, EV_ABORT, EV_N };
+
+typedef struct
+{
+    uint64_t *toa_down, *toa_up, *sfc_dir, *sfc_dif, *sfc_up, *atm_dir, *atm_dif;
+} tallies_t;
+
+static inline void bump(uint64_t* p)
+{
+#pragma omp atomic
+    ++*p;
+}
+
+static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
+                      const float* k_gas, const float* k_cloud, const float* ssa, const float* asy,
+                      uint64_t seed, uint64_t pid, const tallies_t* t, uint64_t* ev)
+{
+    const int itot = sc->itot, jtot = sc->jtot, ktot = sc->ktot;
+    const float xs = (float)itot * sc->dx, ys = (float)jtot * sc->dy;
+    const float inv_xs = 1.0f / xs, inv_ys = 1.0f / ys;
+    const float inv_dx = 1.0f / sc->dx, inv_dy = 1.0f / sc->dy, inv_dz = 1.0f / sc->dz;
+
+    uint32_t w[4];
+
+    /* launch, raytracer_kernels.cu:180-208 */
+    draw(seed, pid, 0u, TAG_LAUNCH, w);
+    float x = xs * u01(w[0]);
+    float y = ys * u01(w[1]);
+    float z = sl->zface[sl->nslab];
+    float ux = sl->sun[0], uy = sl->sun[1], uz = sl->sun[2];
+    float inv_uz = 1.0f / uz;
+    int slab = sl->nslab - 1;
+    int diffuse = 0;
+    {
+        const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot);
+        bump(&t->toa_down[(size_t)i + (size_t)j * itot]);
+    }
+
+    for (uint32_t step = 0;; ++step)
+    {
+        if (step >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
+        {
+            ++ev[EV_ABORT];
+            return;
+        }
+        ++ev[EV_STEP];
+        draw(seed, pid, step, TAG_STEP, w);
+
+        const float inv_k = sl->inv_kmaj[slab];
+        const float tau = free_path_tau(u01(w[0]));
+        float dn = tau * inv_k;                       /* raytracer_kernels.cu:367 */
+        if (!(dn > RT_EPS)) dn = RT_EPS;
+
+        /* distance, in units of the direction vector, to the face this photon is heading for */
+        const int up = uz > 0.0f;
+        const float face = up ? sl->zface[slab + 1] : sl->zface[slab];
+        float t_face = (face - z) * inv_uz;
+        if (!(t_face >= 0.0f)) t_face = INFINITY;
+        const int hit = t_face <= dn;
+        const float tt = hit ? t_face : dn;
+
+        x = wrap_periodic(fmaf(ux, tt, x), xs, inv_xs);
+        y = wrap_periodic(fmaf(uy, tt, y), ys, inv_ys);
+        z = hit ? face : fmaf(uz, tt, z);
+
+        const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot);
+        const size_t ij = (size_t)i + (size_t)j * itot;
+
+        if (hit && !up && slab == 0)
+        {
+            /* surface, raytracer_kernels.cu:455-486 */
+            ++ev[EV_SFC];
+            bump(diffuse ? &t->sfc_dif[ij] : &t->sfc_dir[ij]);
+            if (u01(w[1]) <= sc->albedo)
+            {
+                bump(&t->sfc_up[ij]);
+                const float mu = sqrtf(u01(w[2]));
+                float sa, ca;
+                oracle_sincos2pi(u01(w[3]), &sa, &ca);
+                ux = mu * sa;
+                uy = mu * ca;
+                uz = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
+                inv_uz = 1.0f / uz;
+                diffuse = 1;
+            }
+            else
+                return;
+        }
+        else if (hit && up && slab == sl->nslab - 1)
+        {
+            /* top of atmosphere, raytracer_kernels.cu:487-499 */
+            ++ev[EV_TOA];
+            bump(&t->toa_up[ij]);
+            return;
+        }
+        else if (hit)
+        {
+            /* slab transition, raytracer_kernels.cu:376-415: resample the free path with the
+             * next slab's majorant (memoryless), nothing else happens */
+            ++ev[EV_TRANS];
+            slab += up ? 1 : -1;
+        }
+        else
+        {
+            /* collision test, raytracer_kernels.cu:507-566 */
+            ++ev[EV_COLL];
+            const int k = cell_of(z, inv_dz, ktot);
+            const size_t c = ij + (size_t)k * itot * jtot;
+            const float kt = k_gas[c] + k_cloud[c];
+            const float r = u01(w[1]);
+            const float p_real = kt * inv_k;
+            if (r >= p_real)
+            {
+                /* null collision */
+            }
+            else if (r <= ssa[c] * p_real)
+            {
+                ++ev[EV_REAL]; ++ev[EV_SCAT];
+                uint32_t v[4];
+                draw(seed, pid, step, TAG_SCATTER, v);
+                const int from_cloud = u01(v[0]) < k_cloud[c] / kt;
+                if (from_cloud) ++ev[EV_CSCAT];
+                const float mu = from_cloud ? henyey_mu(asy[c], u01(v[1])) : rayleigh_mu(u01(v[1]));
+                const float sn = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
+
+                /* frame, raytracer_kernels.cu:525-541 */
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                if (fabsf(ux) < fabsf(uy))
+                {
+                    if (fabsf(ux) < fabsf(uz)) ax = 1.0f; else az = 1.0f;
+                }
+                else
+                {
+                    if (fabsf(uy) < fabsf(uz)) ay = 1.0f; else az = 1.0f;
+                }
+                /* dot(t1, dir): the reference's third term is t1.z*t1.z (:73) */
+                const float proj = sc->fixed_dot ? fmaf(az, uz, fmaf(ay, uy, ax * ux))
+                                                 : fmaf(az, az, fmaf(ay, uy, ax * ux));
+                float ox = fmaf(-proj, ux, ax), oy = fmaf(-proj, uy, ay), oz = fmaf(-proj, uz, az);
+                const float inv_len = 1.0f / sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+                ox *= inv_len; oy *= inv_len; oz *= inv_len;
+                const float bx = fmaf(uy, oz, -(uz * oy));
+                const float by = fmaf(uz, ox, -(ux * oz));
+                const float bz = fmaf(ux, oy, -(uy * ox));
+
+                float sp, cp;
+                oracle_sincos2pi(u01(v[2]), &sp, &cp);
+                /* raytracer_kernels.cu:545-546 */
+                const float nx = fmaf(mu, ux, sn * fmaf(sp, ox, cp * bx));
+                const float ny = fmaf(mu, uy, sn * fmaf(sp, oy, cp * by));
+                const float nz = fmaf(mu, uz, sn * fmaf(sp, oz, cp * bz));
+                ux = nx; uy = ny; uz = nz;
+                inv_uz = 1.0f / uz;
+                diffuse = 1;
+            }
+            else
+            {
+                ++ev[EV_REAL]; ++ev[EV_ABS];
+                bump(diffuse ? &t->atm_dif[c] : &t->atm_dir[c]);
+                return;
+            }
+        }
+    }
+}
+
+/* Traces photons [pid_begin, pid_begin + count). Tallies are ADDED to (never cleared).
+ * events (may be NULL) receives EV_N counters. Returns 0 on success. */
+int photon_oracle_trace(const oracle_scene_t* sc,
+                        const float* k_gas, const float* k_cloud, const float* ssa, const float* asy,
+                        uint64_t seed, uint64_t pid_begin, uint64_t count, int nthreads,
+                        uint64_t* toa_down, uint64_t* toa_up,
+                        uint64_t* sfc_dir, uint64_t* sfc_dif, uint64_t* sfc_up,
+                        uint64_t* atm_dir, uint64_t* atm_dif,
+                        uint64_t* events)
+{
+    if (!sc || sc->itot <= 0 || sc->jtot <= 0 || sc->ktot <= 0) return 1;
+    oracle_slabs_t sl;
+    oracle_build_slabs(sc, k_gas, k_cloud, asy, &sl);
+    const tallies_t t = {toa_down, toa_up, sfc_dir, sfc_dif, sfc_up, atm_dir, atm_dif};
+    uint64_t ev_total[EV_N];
+    memset(ev_total, 0, sizeof(ev_total));
+
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+
+#pragma omp parallel
+    {
+        uint64_t ev[EV_N];
+        memset(ev, 0, sizeof(ev));
+#pragma omp for schedule(dynamic, 4096)
+        for (uint64_t n = 0; n < count; ++n)
+            trace_one(sc, &sl, k_gas, k_cloud, ssa, asy, seed, pid_begin + n, &t, ev);
+#pragma omp critical
+        for (int e = 0; e < EV_N; ++e) ev_total[e] += ev[e];
+    }
+    if (events) memcpy(events, ev_total, sizeof(ev_total));
+    return 0;
+}

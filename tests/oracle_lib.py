@@ -1,0 +1,183 @@
+"""ctypes bindings of oracle/liboracle.so for the tests (and bench.py's cpu_baseline leg).
+
+The oracle is the CHECKER. Nothing under raytracer_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "raytracer_3d_ref")
+
+TALLY_NAMES = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up",
+               "atmos_direct", "atmos_diffuse")
+EVENT_NAMES = ("steps", "collision_tests", "real", "scatter", "cloud_scatter", "surface", "toa",
+               "absorb", "transition", "abort")
+
+
+class OracleScene(C.Structure):
+    _fields_ = [("itot", C.c_int), ("jtot", C.c_int), ("ktot", C.c_int),
+                ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
+                ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
+                ("fixed_dot", C.c_int)]
+
+
+class OracleSlabs(C.Structure):
+    _fields_ = [("nslab", C.c_int), ("zface", C.c_float * 4), ("kmaj", C.c_float * 3),
+                ("inv_kmaj", C.c_float * 3), ("k_lo", C.c_int), ("k_hi", C.c_int),
+                ("sun", C.c_float * 3)]
+
+
+_lib = None
+
+
+def build_oracle() -> None:
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_oracle()
+        _lib = C.CDLL(LIB_PATH)
+        u64p = C.POINTER(C.c_uint64)
+        f32p = C.POINTER(C.c_float)
+        f64p = C.POINTER(C.c_double)
+        _lib.cpu_ref_trace.restype = C.c_int
+        _lib.cpu_ref_trace.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [f64p] * 4 + [C.c_double] * 3 + \
+            [C.c_uint64, C.c_int, C.c_int] + [u64p] * 8
+        _lib.photon_oracle_trace.restype = C.c_int
+        _lib.photon_oracle_trace.argtypes = [C.POINTER(OracleScene)] + [f32p] * 4 + \
+            [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int] + [u64p] * 8
+        _lib.oracle_build_slabs.restype = None
+        _lib.oracle_build_slabs.argtypes = [C.POINTER(OracleScene)] + [f32p] * 3 + [C.POINTER(OracleSlabs)]
+        _lib.oracle_philox4x32_10.restype = None
+        _lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        _lib.oracle_logf.restype = C.c_float
+        _lib.oracle_logf.argtypes = [C.c_float]
+        _lib.oracle_cbrtf.restype = C.c_float
+        _lib.oracle_cbrtf.argtypes = [C.c_float]
+        _lib.oracle_sincos2pi.restype = None
+        _lib.oracle_sincos2pi.argtypes = [C.c_float, f32p, f32p]
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def new_tallies(scene):
+    out = {}
+    for n in TALLY_NAMES:
+        shape = (scene.ktot, scene.jtot, scene.itot) if n.startswith("atmos") else (scene.jtot, scene.itot)
+        out[n] = np.zeros(shape, dtype=np.uint64)
+    return out
+
+
+def oracle_scene(scene, fixed_dot=False) -> OracleScene:
+    f = np.float32
+    return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
+                       f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
+                       scene.albedo, int(fixed_dot))
+
+
+def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False):
+    """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
+    t = tallies if tallies is not None else new_tallies(scene)
+    ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
+    sc = oracle_scene(scene, fixed_dot)
+    fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
+    rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
+                                   seed, pid_begin, count, nthreads,
+                                   *[_p(t[n], C.c_uint64) for n in TALLY_NAMES], _p(ev, C.c_uint64))
+    if rc != 0:
+        raise RuntimeError(f"photon_oracle_trace failed: {rc}")
+    return t, dict(zip(EVENT_NAMES, (int(v) for v in ev)))
+
+
+def oracle_slabs(scene) -> OracleSlabs:
+    sc = oracle_scene(scene)
+    sl = OracleSlabs()
+    kg, kc, _, asy = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
+    lib().oracle_build_slabs(C.byref(sc), _p(kg, C.c_float), _p(kc, C.c_float), _p(asy, C.c_float), C.byref(sl))
+    return sl
+
+
+def cpu_ref(scene_f64, n_photons, nthreads=1, serial_seed=False):
+    """Run oracle/cpu_ref.cpp on double-precision fields.
+
+    scene_f64: dict with itot,jtot,ktot,dx,dy,dz,k_gas,k_cloud,ssa,asy (float64 arrays),
+    albedo, zenith_rad, azimuth_rad. Returns (tallies, events[8])."""
+    s = scene_f64
+    class _S:  # shape helper
+        itot, jtot, ktot = s["itot"], s["jtot"], s["ktot"]
+    t = new_tallies(_S)
+    ev = np.zeros(8, dtype=np.uint64)
+    arrs = [np.ascontiguousarray(s[k], dtype=np.float64) for k in ("k_gas", "k_cloud", "ssa", "asy")]
+    rc = lib().cpu_ref_trace(s["itot"], s["jtot"], s["ktot"], s["dx"], s["dy"], s["dz"],
+                             *[_p(a, C.c_double) for a in arrs],
+                             s["albedo"], s["zenith_rad"], s["azimuth_rad"],
+                             n_photons, nthreads, int(serial_seed),
+                             *[_p(t[n], C.c_uint64) for n in TALLY_NAMES], _p(ev, C.c_uint64))
+    if rc != 0:
+        raise RuntimeError(f"cpu_ref_trace failed: {rc}")
+    return t, ev
+
+
+def block_cloud_f64():
+    """The built-in scene of raytracer_3d.cpp:168-220 in double precision, value for value."""
+    itot = jtot = ktot = 128
+    dx = dy = 50.0
+    dz = 25.0
+    k_ext_gas, ssa_gas, asy_gas = 1.0e-4, 0.5, 0.0
+    k_ext_cloud, ssa_cloud, asy_cloud = 5.0e-3, 0.9, 0.85
+    k_gas = np.full((ktot, jtot, itot), k_ext_gas)
+    k_cloud = np.zeros((ktot, jtot, itot))
+    ssa = np.full((ktot, jtot, itot), ssa_gas)
+    asy = np.zeros((ktot, jtot, itot))
+    x = (np.arange(itot) + 0.5) * dx
+    y = (np.arange(jtot) + 0.5) * dy
+    z = (np.arange(ktot) + 0.5) * dz
+    m = ((z > 1000.) & (z < 1500.))[:, None, None] & ((y > 2700.) & (y < 3700.))[None, :, None] \
+        & ((x > 4000.) & (x < 5000.))[None, None, :]
+    k_cloud[m] = k_ext_cloud
+    ssa[m] = (ssa_gas * k_ext_gas + ssa_cloud * k_ext_cloud) / (k_ext_gas + k_ext_cloud)
+    asy[m] = (asy_gas * ssa_gas * k_ext_gas + asy_cloud * ssa_cloud * k_ext_cloud) \
+        / (ssa_gas * k_ext_gas + ssa_cloud * k_ext_cloud)
+    return dict(itot=itot, jtot=jtot, ktot=ktot, dx=dx, dy=dy, dz=dz, k_gas=k_gas, k_cloud=k_cloud,
+                ssa=ssa, asy=asy, albedo=0.2, zenith_rad=50. * (math.pi / 180.), azimuth_rad=20. * (math.pi / 180.))
+
+
+def scene_to_f64(scene):
+    """float32 Scene -> the dict cpu_ref() takes (values widened, not recomputed)."""
+    return dict(itot=scene.itot, jtot=scene.jtot, ktot=scene.ktot, dx=scene.dx, dy=scene.dy, dz=scene.dz,
+                k_gas=scene.k_gas.astype(np.float64), k_cloud=scene.k_cloud.astype(np.float64),
+                ssa=scene.ssa.astype(np.float64), asy=scene.asy.astype(np.float64), albedo=scene.albedo,
+                zenith_rad=scene.zenith_deg * (math.pi / 180.), azimuth_rad=scene.azimuth_deg * (math.pi / 180.))
+
+
+def run_reference_binary(arg: int, workdir: str, nthreads: int = 1):
+    """Run the compiled reference (oracle/_ref/raytracer_3d_ref <arg>) in workdir; returns tallies."""
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    subprocess.run([REF_BIN, str(arg)], cwd=workdir, check=True, env=env, stdout=subprocess.DEVNULL)
+    out = {}
+    for n in TALLY_NAMES:
+        shape = (128, 128, 128) if n.startswith("atmos") else (128, 128)
+        out[n] = np.fromfile(os.path.join(workdir, n + ".bin"), dtype=np.uint64).reshape(shape)
+    return out
+
+
+def balance(t) -> int:
+    """Photon balance of plot_results_3d.py:41-44 (must be exactly 0)."""
+    inn = int(t["toa_down"].sum())
+    out = int(t["surface_down_direct"].sum()) + int(t["surface_down_diffuse"].sum()) - int(t["surface_up"].sum()) \
+        + int(t["toa_up"].sum()) + int(t["atmos_direct"].sum()) + int(t["atmos_diffuse"].sum())
+    return inn - out
