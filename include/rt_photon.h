@@ -1,0 +1,178 @@
+/* rt_photon.h — C ABI of the MI355X photon-tracing library (librt_photon.so).
+ *
+ * The reference (Chiil/raytracer) has no plugin or FFI layer: its host drivers #include the CUDA
+ * kernels and launch them directly. This header is the boundary a drop-in replacement for that
+ * path exports: each entry point names the reference code it stands in for (file:line relative
+ * to /root/reference/src/). Plain pointers and sizes only; every call returns 0 on success and a
+ * non-zero rt_status otherwise, with a message available from rt_last_error() (the reference
+ * prints and exit()s instead, raytracer_kernels.cu:101-110). No exceptions cross this boundary.
+ *
+ * Ownership: the context owns all device memory and frees it in rt_destroy (the reference never
+ * frees, free_gpu of raytracer_kernels.cu:123-128 is uncalled). Host pointers handed to the
+ * library stay the caller's. Threading: one context per GPU; a context is not thread-safe, calls
+ * on different contexts are independent.
+ */
+#ifndef RT_PHOTON_H
+#define RT_PHOTON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+enum rt_status
+{
+    RT_OK = 0,
+    RT_ERR_ARG = 1,      /* bad argument */
+    RT_ERR_HIP = 2,      /* a HIP runtime call failed */
+    RT_ERR_STATE = 3,    /* call order: optics or scene not set */
+    RT_ERR_ABORTED = 4   /* photons were abandoned by the step guard (non-finite state) */
+};
+
+/* Order of the seven tally arrays everywhere in this API (file names of
+ * raytracer_3d.cu:197-203 without ".bin"). The first five hold itot*jtot counts laid out [j][i],
+ * the last two itot*jtot*ktot counts laid out [k][j][i]; all uint64. */
+enum rt_tally
+{
+    RT_TOA_DOWN = 0,
+    RT_TOA_UP = 1,
+    RT_SURFACE_DOWN_DIRECT = 2,
+    RT_SURFACE_DOWN_DIFFUSE = 3,
+    RT_SURFACE_UP = 4,
+    RT_ATMOS_DIRECT = 5,
+    RT_ATMOS_DIFFUSE = 6,
+    RT_N_TALLIES = 7
+};
+
+/* Event counters of one or more rt_trace calls (rt_get_events). They feed the algorithmic-bytes
+ * figure of the roofline. */
+enum rt_event
+{
+    RT_EV_STEPS = 0,        /* loop iterations: one free-path sample each */
+    RT_EV_COLLISION_TESTS,  /* gathers of k_tot */
+    RT_EV_REAL,             /* non-null collisions (gather of ssa) */
+    RT_EV_SCATTER,          /* scatterings (gather of asy, k_cloud) */
+    RT_EV_CLOUD_SCATTER,
+    RT_EV_SURFACE,          /* surface arrivals */
+    RT_EV_TOA,              /* escapes at the top */
+    RT_EV_ABSORB,           /* absorptions in the atmosphere */
+    RT_EV_TRANSITION,       /* majorant-region crossings */
+    RT_EV_ABORT,            /* photons abandoned by the step/NaN guard; must stay 0 */
+    RT_N_EVENTS
+};
+
+/* What the pre-pass derives from the optical-property grids: the horizontal slabs used for
+ * null-collision tracking. Replaces cloud_dims of cloud_mask_kernel (raytracer_kernels.cu:263-305)
+ * and k_ext_null / k_ext_null_gas of raytracer_3d_io.cu:60-77. */
+typedef struct rt_slab_info
+{
+    int nslab;          /* 1..3 non-empty slabs, bottom to top */
+    float zface[4];     /* nslab+1 face heights (m) */
+    float kmaj[3];      /* majorant extinction (1/m) per slab */
+    int k_lo, k_hi;     /* lowest / highest level holding any asy > 0; -1 if none */
+    float cloud_min;    /* = k_lo*dz,      cloud_dims[0] of the reference (0 if none) */
+    float cloud_max;    /* = (k_hi+1)*dz,  cloud_dims[1] of the reference (0 if none) */
+    float sun[3];       /* direction cosines of the direct beam */
+} rt_slab_info;
+
+/* Message of the last failed call on this thread. */
+const char* rt_last_error(void);
+
+/* Number of visible GPUs (hipGetDeviceCount). */
+int rt_device_count(int* count);
+
+/* Creates a context on GPU `device_id` for an itot x jtot x ktot grid with spacings dx,dy,dz (m)
+ * and allocates the seven tally arrays, zeroed. Stands in for the allocation block of
+ * run_ray_tracer, raytracer_3d.cu:81-104 (allocate_gpu, raytracer_kernels.cu:113-120). */
+int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, float dz,
+              rt_context** out);
+
+/* Frees everything the context owns. (free_gpu, raytracer_kernels.cu:123-128.) */
+int rt_destroy(rt_context* ctx);
+
+/* Uploads the four optical-property fields (host pointers, itot*jtot*ktot float32 each, [k][j][i],
+ * the make_binary.py file layout) and runs the device pre-pass that packs them for the tracer and
+ * derives majorants and cloud bounds. Stands in for copy_to_gpu of the two grids
+ * (raytracer_3d.cu:83-87), the host loop of raytracer_3d_io.cu:60-77 and cloud_mask_kernel
+ * (raytracer_kernels.cu:263-305, launched at raytracer_3d.cu:116-123). */
+int rt_upload_optics(rt_context* ctx, const float* k_ext_gas, const float* k_ext_cloud,
+                     const float* ssa, const float* asy);
+
+/* Same, from device pointers already resident on the context's GPU (no PCIe in the path). */
+int rt_upload_optics_device(rt_context* ctx, const float* d_k_ext_gas, const float* d_k_ext_cloud,
+                            const float* d_ssa, const float* d_asy);
+
+/* Solar geometry and surface albedo: zenith and azimuth in radians (as float, the way
+ * raytracer_3d.cu:25-30 holds them) and the Lambertian albedo (raytracer_3d.cu:24). */
+int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float albedo);
+
+/* Options by name:
+ *   "fixed_dot"      0 (default): dot() as the reference writes it, raytracer_kernels.cu:70-74;
+ *                    1: the mathematically intended v1.z*v2.z
+ *   "blocks_per_cu"  workgroups of 256 lanes per compute unit of the persistent launch (default 8)
+ *   "stats"          1: rt_trace also counts events (rt_get_events); 0 (default): it does not */
+int rt_set_option(rt_context* ctx, const char* name, long long value);
+
+/* Launch on this HIP stream (a hipStream_t) from now on; NULL = the null stream. */
+int rt_set_stream(rt_context* ctx, void* hip_stream);
+
+/* Traces photons with IDs [photon_id_begin, photon_id_begin + photon_count) and ADDS their
+ * events to the device tallies (the restart-friendly accumulation raytracer_3d.cu:89 intends).
+ * Every random number is Philox4x32-10(key = seed, counter = (photon id, step, purpose)), so the
+ * tallies of a photon range do not depend on how it is split over calls, launches or GPUs.
+ * Asynchronous on the context's stream. Stands in for the ray_tracer_kernel launch,
+ * raytracer_3d.cu:151-163 (kernel: raytracer_kernels.cu:307-569). */
+int rt_trace(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t photon_count);
+
+/* Blocks until the context's stream is idle (cudaDeviceSynchronize at raytracer_3d.cu:165) and
+ * reports RT_ERR_ABORTED if any photon hit the step guard. */
+int rt_synchronize(rt_context* ctx);
+
+/* Copies the seven tally arrays to caller-allocated host arrays, out[rt_tally].
+ * (copy_from_gpu, raytracer_3d.cu:174-180.) Synchronises first. */
+int rt_download_tallies(rt_context* ctx, uint64_t* const out[RT_N_TALLIES]);
+
+/* Adds caller-provided counts into the device tallies (restart: raytracer_3d.cu:98-104 copies
+ * the host arrays up "to enable restarts later"). */
+int rt_upload_tallies(rt_context* ctx, const uint64_t* const in[RT_N_TALLIES]);
+
+/* Zeroes the device tallies and event counters. */
+int rt_reset_tallies(rt_context* ctx);
+
+/* The concatenated device tally buffer: 5*itot*jtot + 2*itot*jtot*ktot uint64 words in rt_tally
+ * order. For the one collective of the multi-GPU path (sum all-reduce over RCCL, done by the
+ * host side on this pointer). No counterpart in the reference (single GPU only). */
+int rt_tally_device_buffer(rt_context* ctx, void** device_ptr, size_t* n_words);
+
+/* Makes the context accumulate into a caller-owned device buffer of the same layout (e.g. a
+ * tensor the host framework allocated, so that it can hand it to its collective). The buffer must
+ * outlive the context or a later rebind; its current contents are kept (not zeroed). */
+int rt_bind_tally_buffer(rt_context* ctx, void* device_ptr, size_t n_words);
+
+/* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
+int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
+
+/* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
+ * but RT_EV_ABORT). Synchronises first. */
+int rt_get_events(rt_context* ctx, uint64_t out[RT_N_EVENTS]);
+
+/* Device time of the most recent rt_trace launch in milliseconds (HIP events recorded on the
+ * context's stream around the kernel; synchronises on the stop event). Mirrors the timer of
+ * raytracer_3d.cu:149-169. */
+int rt_last_trace_ms(rt_context* ctx, float* ms);
+
+/* Test hook: Philox4x32-10 on the device, n counter blocks (4 words each) under one key. */
+int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint32_t key[2], uint32_t* out);
+
+/* Test hook: evaluates the device math (0 = log, 1 = cbrt, 2 = sin(2*pi*x), 3 = cos(2*pi*x)) on n
+ * host floats. */
+int rt_selftest_math(int device_id, int which, const float* in, size_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_PHOTON_H */

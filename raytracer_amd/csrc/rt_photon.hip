@@ -1,0 +1,761 @@
+// rt_photon.hip — MI355X (gfx950) photon tracer: kernels and the C ABI of include/rt_photon.h.
+//
+// Hot path replaced: ray_tracer_kernel of the reference (raytracer_kernels.cu:307-569) and the
+// staging code around its launch (raytracer_3d.cu:81-180, raytracer_3d_io.cu:60-77).
+//
+// Design:
+//  * one photon per lane, the whole photon state in VGPRs (the reference keeps it in global
+//    memory, raytracer_kernels.cu:360-473), a persistent grid sized to the chip, lanes pull the
+//    next photon ID the moment their photon ends (regeneration, raytracer_kernels.cu:477-498);
+//  * Philox4x32-10 keyed on (seed, photon id, step, purpose): tallies are integers, so the sum
+//    is independent of the launch shape, of the split over calls and of the GPU count;
+//  * optical properties as structure-of-arrays: k_tot (read at every collision test), ssa (only
+//    at real collisions), {asy, k_cloud} (only at scatterings);
+//  * null-collision tracking with one majorant per horizontal slab (below / in / above the cloud
+//    layer, the reference's scheme, raytracer_kernels.cu:360-415), restated with an explicit slab
+//    index and the parametric distance to the next slab face instead of in-place nudging.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see __graft_entry__.py).
+
+#include "rt_device.hip.h"
+#include "../../include/rt_photon.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RT_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------
+// Kernel arguments of the tracer (by value: they live in SGPRs).
+struct TraceArgs
+{
+    const float* k_tot;       // gas + cloud extinction per cell [k][j][i]
+    const float* ssa;         // single-scattering albedo per cell
+    const float2* scat;       // {asy, k_cloud} per cell
+    unsigned long long* tallies;  // concatenated, rt_tally order
+    unsigned long long* events;   // RT_N_EVENTS counters
+    uint64_t seed;
+    uint64_t pid_begin;
+    uint64_t pid_end;
+    int itot, jtot, ktot;
+    uint32_t ncol;
+    uint32_t ncell;
+    float xs, ys, inv_xs, inv_ys, inv_dx, inv_dy, inv_dz;
+    float albedo;
+    float sun_x, sun_y, sun_z, inv_sun_z;
+    int nslab;
+    float zface[4];
+    float inv_kmaj[3];
+};
+
+__device__ __forceinline__ void tally_add(unsigned long long* p)
+{
+    // no-return 64-bit global atomic (write_photon_out, raytracer_kernels.cu:256-261)
+    __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
+// The photon life cycle. One lane = one photon at a time; the loop body is one free-path sample.
+template <bool FIXED_DOT, bool STATS>
+__global__ void __launch_bounds__(kBlock)
+rt_trace_kernel(const TraceArgs a)
+{
+    using namespace rt;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint64_t next_pid = a.pid_begin + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+
+    const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
+    const float ztop = a.zface[a.nslab];
+
+    // photon state
+    float x = 0.f, y = 0.f, z = 0.f, ux = 0.f, uy = 0.f, uz = -1.f, inv_uz = -1.f;
+    uint32_t pid_lo = 0, pid_hi = 0, step = 0;
+    int slab = 0;
+    bool diffuse = false;
+    bool alive = false;
+
+    uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
+             ev_abs = 0, ev_trans = 0;
+
+    for (;;)
+    {
+        if (!alive)
+        {
+            if (next_pid >= a.pid_end)
+                break;
+            // launch at the top of the domain, raytracer_kernels.cu:180-208
+            pid_lo = (uint32_t)next_pid;
+            pid_hi = (uint32_t)(next_pid >> 32);
+            next_pid += stride;
+            const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, TAG_LAUNCH, key0, key1);
+            x = a.xs * u01(w.x);
+            y = a.ys * u01(w.y);
+            z = ztop;
+            ux = a.sun_x; uy = a.sun_y; uz = a.sun_z; inv_uz = a.inv_sun_z;
+            slab = a.nslab - 1;
+            diffuse = false;
+            step = 0;
+            alive = true;
+            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+            tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+        }
+
+        if (step >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
+        {
+            tally_add(&a.events[RT_EV_ABORT]);
+            alive = false;
+            continue;
+        }
+        if (STATS) ++ev_step;
+
+        const u32x4 w = philox4x32_10(pid_lo, pid_hi, step, TAG_STEP, key0, key1);
+
+        const float inv_k = slab == 0 ? a.inv_kmaj[0] : (slab == 1 ? a.inv_kmaj[1] : a.inv_kmaj[2]);
+        const float tau = free_path_tau(u01(w.x));
+        float dn = tau * inv_k;                         // raytracer_kernels.cu:367
+        dn = (dn > RT_EPS) ? dn : RT_EPS;
+
+        // parametric distance to the slab face this photon is heading for
+        const bool up = uz > 0.0f;
+        const int fi = up ? slab + 1 : slab;
+        const float face = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3]));
+        float t_face = (face - z) * inv_uz;
+        t_face = (t_face >= 0.0f) ? t_face : __builtin_inff();
+        const bool hit = t_face <= dn;
+        const float tt = hit ? t_face : dn;
+
+        x = wrap_periodic(fma_(ux, tt, x), a.xs, a.inv_xs);
+        y = wrap_periodic(fma_(uy, tt, y), a.ys, a.inv_ys);
+        z = hit ? face : fma_(uz, tt, z);
+
+        const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+        const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+
+        if (hit && !up && slab == 0)
+        {
+            // surface, raytracer_kernels.cu:455-486
+            if (STATS) ++ev_sfc;
+            tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]);
+            if (u01(w.y) <= a.albedo)
+            {
+                tally_add(&a.tallies[4u * a.ncol + ij]);
+                const float mu = __builtin_sqrtf(u01(w.z));
+                float sa, ca;
+                rt_sincos2pi(u01(w.w), sa, ca);
+                ux = mu * sa;
+                uy = mu * ca;
+                uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+                inv_uz = 1.0f / uz;
+                diffuse = true;
+            }
+            else
+                alive = false;
+        }
+        else if (hit && up && slab == a.nslab - 1)
+        {
+            // top of the atmosphere, raytracer_kernels.cu:487-499
+            if (STATS) ++ev_toa;
+            tally_add(&a.tallies[a.ncol + ij]);
+            alive = false;
+        }
+        else if (hit)
+        {
+            // slab transition, raytracer_kernels.cu:376-415
+            if (STATS) ++ev_trans;
+            slab += up ? 1 : -1;
+        }
+        else
+        {
+            // collision test, raytracer_kernels.cu:507-566
+            if (STATS) ++ev_coll;
+            const int k = cell_of(z, a.inv_dz, a.ktot);
+            const uint32_t c = ij + (uint32_t)k * a.ncol;
+            const float kt = a.k_tot[c];
+            const float r = u01(w.y);
+            const float p_real = kt * inv_k;
+            if (r >= p_real)
+            {
+                // null collision
+            }
+            else if (r <= a.ssa[c] * p_real)
+            {
+                if (STATS) { ++ev_real; ++ev_scat; }
+                const u32x4 v = philox4x32_10(pid_lo, pid_hi, step, TAG_SCATTER, key0, key1);
+                const float2 ak = a.scat[c];                    // {asy, k_cloud}
+                const bool from_cloud = u01(v.x) < ak.y / kt;
+                if (STATS && from_cloud) ++ev_cscat;
+                const float mu = from_cloud ? henyey_mu(ak.x, u01(v.y)) : rayleigh_mu(u01(v.y));
+                const float sn = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+
+                // frame, raytracer_kernels.cu:525-541
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
+                if (fx < fy)
+                {
+                    if (fx < fz) ax = 1.0f; else az = 1.0f;
+                }
+                else
+                {
+                    if (fy < fz) ay = 1.0f; else az = 1.0f;
+                }
+                // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
+                const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
+                                             : fma_(az, az, fma_(ay, uy, ax * ux));
+                float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
+                const float inv_len = 1.0f / __builtin_sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
+                ox *= inv_len; oy *= inv_len; oz *= inv_len;
+                const float bx = fma_(uy, oz, -(uz * oy));
+                const float by = fma_(uz, ox, -(ux * oz));
+                const float bz = fma_(ux, oy, -(uy * ox));
+
+                float sp, cp;
+                rt_sincos2pi(u01(v.z), sp, cp);
+                const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
+                const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
+                const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
+                ux = nx; uy = ny; uz = nz;
+                inv_uz = 1.0f / uz;
+                diffuse = true;
+            }
+            else
+            {
+                if (STATS) { ++ev_real; ++ev_abs; }
+                tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncell : 0u) + c]);
+                alive = false;
+            }
+        }
+        ++step;
+    }
+
+    if (STATS)
+    {
+        // one atomic per counter per lane at kernel end (stats launches are not the timed ones)
+        const uint32_t ev[9] = {ev_step, ev_coll, ev_real, ev_scat, ev_cscat, ev_sfc, ev_toa, ev_abs, ev_trans};
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+            if (ev[e])
+                __hip_atomic_fetch_add(&a.events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pre-pass: pack the four input fields for the tracer and reduce per level
+//   lev_max[k]   = max over the level of gas + cloud          (raytracer_3d_io.cu:73-76)
+//   lev_cloud[k] = 1 if any asy > 0 on the level              (raytracer_kernels.cu:274-284)
+// One workgroup per (level, chunk); float max via integer atomicMax is exact for values >= 0.
+__global__ void __launch_bounds__(kBlock)
+rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_cloud,
+               const float* __restrict__ asy,
+               float* __restrict__ k_tot, float2* __restrict__ scat,
+               unsigned int* __restrict__ lev_max_bits, unsigned int* __restrict__ lev_cloud,
+               uint32_t ncol, int chunks_per_level)
+{
+    const int k = blockIdx.x / chunks_per_level;
+    const int chunk = blockIdx.x % chunks_per_level;
+    const size_t base = (size_t)k * ncol;
+    float m = 0.0f;
+    unsigned int cloudy = 0;
+    for (uint32_t c = (uint32_t)chunk * kBlock + threadIdx.x; c < ncol; c += (uint32_t)chunks_per_level * kBlock)
+    {
+        const float g = k_gas[base + c], cl = k_cloud[base + c], as = asy[base + c];
+        const float kt = g + cl;
+        k_tot[base + c] = kt;
+        scat[base + c] = make_float2(as, cl);
+        m = kt > m ? kt : m;
+        cloudy |= as > 0.0f ? 1u : 0u;
+    }
+    // wave reduction (64 lanes), then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        const float o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    const unsigned long long any = __ballot(cloudy != 0);
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicMax(&lev_max_bits[k], __float_as_uint(m));
+        if (any) atomicOr(&lev_cloud[k], 1u);
+    }
+}
+
+__global__ void rt_add_u64_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+
+__global__ void rt_selftest_philox_kernel(const uint32_t* ctr, size_t n, uint32_t k0, uint32_t k1, uint32_t* out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n)
+    {
+        const rt::u32x4 r = rt::philox4x32_10(ctr[4 * t], ctr[4 * t + 1], ctr[4 * t + 2], ctr[4 * t + 3], k0, k1);
+        out[4 * t] = r.x; out[4 * t + 1] = r.y; out[4 * t + 2] = r.z; out[4 * t + 3] = r.w;
+    }
+}
+
+__global__ void rt_selftest_math_kernel(int which, const float* in, size_t n, float* out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n)
+    {
+        const float v = in[t];
+        float s, c;
+        switch (which)
+        {
+            case 0: out[t] = rt::rt_log(v); break;
+            case 1: out[t] = rt::rt_cbrt(v); break;
+            case 2: rt::rt_sincos2pi(v, s, c); out[t] = s; break;
+            case 3: rt::rt_sincos2pi(v, s, c); out[t] = c; break;
+            case 4: out[t] = rt::rayleigh_mu(v); break;
+            default: out[t] = rt::henyey_mu(0.85f, v); break;
+        }
+    }
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+struct rt_context
+{
+    int device = 0;
+    int itot = 0, jtot = 0, ktot = 0;
+    float dx = 0, dy = 0, dz = 0;
+    size_t ncol = 0, ncell = 0, nwords = 0;
+    int cu_count = 256;
+
+    float* d_k_tot = nullptr;
+    float* d_ssa = nullptr;
+    float2* d_scat = nullptr;
+    unsigned long long* d_tallies = nullptr;
+    bool owns_tallies = false;
+    unsigned long long* d_events = nullptr;
+
+    bool have_optics = false, have_scene = false;
+    std::vector<float> lev_max;
+    std::vector<unsigned int> lev_cloud;
+    rt_slab_info slabs{};
+    float inv_kmaj[3] = {0, 0, 0};
+    float albedo = 0.2f, zenith = 0, azimuth = 0;
+
+    bool fixed_dot = false, stats = false;
+    int blocks_per_cu = 8;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace
+{
+// Slabs from the per-level reductions: cloud layer = levels k_lo..k_hi holding any asy > 0
+// (cloud_mask_kernel, raytracer_kernels.cu:263-305, without its indexing bugs); majorant of a
+// slab = max of gas + cloud over its levels (raytracer_3d_io.cu:60-77 takes it over the domain).
+void build_slabs(rt_context* c)
+{
+    int k_lo = -1, k_hi = -1;
+    for (int k = 0; k < c->ktot; ++k)
+        if (c->lev_cloud[k]) { if (k_lo < 0) k_lo = k; k_hi = k; }
+    int lo[3], hi[3], n = 0;
+    if (k_lo < 0) { lo[0] = 0; hi[0] = c->ktot; n = 1; }
+    else
+    {
+        if (k_lo > 0) { lo[n] = 0; hi[n] = k_lo; ++n; }
+        lo[n] = k_lo; hi[n] = k_hi + 1; ++n;
+        if (k_hi + 1 < c->ktot) { lo[n] = k_hi + 1; hi[n] = c->ktot; ++n; }
+    }
+    rt_slab_info& s = c->slabs;
+    s.nslab = n; s.k_lo = k_lo; s.k_hi = k_hi;
+    s.cloud_min = k_lo < 0 ? 0.0f : (float)k_lo * c->dz;
+    s.cloud_max = k_lo < 0 ? 0.0f : (float)(k_hi + 1) * c->dz;
+    for (int i = 0; i < 3; ++i) { s.kmaj[i] = 0.0f; c->inv_kmaj[i] = 0.0f; }
+    for (int i = 0; i < n; ++i)
+    {
+        float m = 0.0f;
+        for (int k = lo[i]; k < hi[i]; ++k) m = c->lev_max[k] > m ? c->lev_max[k] : m;
+        s.kmaj[i] = m;
+        c->inv_kmaj[i] = 1.0f / m;
+        s.zface[i] = (float)lo[i] * c->dz;
+    }
+    s.zface[n] = (float)c->ktot * c->dz;
+    for (int i = n + 1; i < 4; ++i) s.zface[i] = s.zface[n];
+}
+
+int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, const float* d_ssa, const float* d_asy)
+{
+    unsigned int* d_lev = nullptr;
+    RT_HIP(hipMalloc(&d_lev, sizeof(unsigned int) * 2 * c->ktot));
+    RT_HIP(hipMemsetAsync(d_lev, 0, sizeof(unsigned int) * 2 * c->ktot, c->stream));
+    int chunks = (int)((c->ncol + kBlock * 8 - 1) / (kBlock * 8));
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(rt_pack_kernel, dim3(c->ktot * chunks), dim3(kBlock), 0, c->stream,
+                       d_gas, d_cloud, d_asy, c->d_k_tot, c->d_scat, d_lev, d_lev + c->ktot,
+                       (uint32_t)c->ncol, chunks);
+    RT_HIP(hipGetLastError());
+    if (d_ssa != c->d_ssa)
+        RT_HIP(hipMemcpyAsync(c->d_ssa, d_ssa, sizeof(float) * c->ncell, hipMemcpyDeviceToDevice, c->stream));
+    std::vector<unsigned int> lev(2 * c->ktot);
+    RT_HIP(hipMemcpyAsync(lev.data(), d_lev, sizeof(unsigned int) * 2 * c->ktot, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    RT_HIP(hipFree(d_lev));
+    c->lev_max.resize(c->ktot);
+    c->lev_cloud.resize(c->ktot);
+    for (int k = 0; k < c->ktot; ++k)
+    {
+        memcpy(&c->lev_max[k], &lev[k], 4);
+        c->lev_cloud[k] = lev[c->ktot + k];
+    }
+    build_slabs(c);
+    c->have_optics = true;
+    return RT_OK;
+}
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_device_count(int* count)
+{
+    if (!count) return fail(RT_ERR_ARG, "rt_device_count: null pointer");
+    RT_HIP(hipGetDeviceCount(count));
+    return RT_OK;
+}
+
+int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, float dz, rt_context** out)
+{
+    if (!out) return fail(RT_ERR_ARG, "rt_create: null output pointer");
+    *out = nullptr;
+    if (itot <= 0 || jtot <= 0 || ktot <= 0 || !(dx > 0) || !(dy > 0) || !(dz > 0))
+        return fail(RT_ERR_ARG, "rt_create: grid %dx%dx%d with spacing %g,%g,%g is not valid", itot, jtot, ktot, dx, dy, dz);
+    const size_t ncol = (size_t)itot * jtot, ncell = ncol * ktot;
+    if (5 * ncol + 2 * ncell >= (1ull << 32))
+        return fail(RT_ERR_ARG, "rt_create: %zu cells exceed the 32-bit tally index of this build", ncell);
+    int ndev = 0;
+    RT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(RT_ERR_ARG, "rt_create: device %d not in [0,%d)", device_id, ndev);
+    RT_HIP(hipSetDevice(device_id));
+
+    rt_context* c = new rt_context;
+    c->device = device_id;
+    c->itot = itot; c->jtot = jtot; c->ktot = ktot;
+    c->dx = dx; c->dy = dy; c->dz = dz;
+    c->ncol = ncol; c->ncell = ncell; c->nwords = 5 * ncol + 2 * ncell;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        c->cu_count = prop.multiProcessorCount;
+
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&c->d_k_tot, sizeof(float) * ncell);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ssa, sizeof(float) * ncell);
+    if (e == hipSuccess) e = hipMalloc(&c->d_scat, sizeof(float2) * ncell);
+    if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
+    if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * RT_N_EVENTS);
+    if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
+    if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * RT_N_EVENTS);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e != hipSuccess)
+    {
+        c->owns_tallies = true;
+        rt_destroy(c);
+        return fail(RT_ERR_HIP, "rt_create: allocation failed: %s", hipGetErrorString(e));
+    }
+    c->owns_tallies = true;
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context* c)
+{
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    if (c->d_k_tot) (void)hipFree(c->d_k_tot);
+    if (c->d_ssa) (void)hipFree(c->d_ssa);
+    if (c->d_scat) (void)hipFree(c->d_scat);
+    if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
+    if (c->d_events) (void)hipFree(c->d_events);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    delete c;
+    return RT_OK;
+}
+
+int rt_upload_optics(rt_context* c, const float* k_gas, const float* k_cloud, const float* ssa, const float* asy)
+{
+    if (!c || !k_gas || !k_cloud || !ssa || !asy) return fail(RT_ERR_ARG, "rt_upload_optics: null pointer");
+    RT_HIP(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * c->ncell;
+    float* tmp = nullptr;   // gas | cloud | asy staging; ssa goes straight to its final array
+    RT_HIP(hipMalloc(&tmp, 3 * bytes));
+    hipError_t e = hipMemcpyAsync(tmp, k_gas, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + c->ncell, k_cloud, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * c->ncell, asy, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_ssa, ssa, bytes, hipMemcpyHostToDevice, c->stream);
+    int rc = RT_OK;
+    if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_upload_optics: copy failed: %s", hipGetErrorString(e));
+    else rc = pack_from_device(c, tmp, tmp + c->ncell, c->d_ssa, tmp + 2 * c->ncell);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int rt_upload_optics_device(rt_context* c, const float* d_gas, const float* d_cloud, const float* d_ssa, const float* d_asy)
+{
+    if (!c || !d_gas || !d_cloud || !d_ssa || !d_asy) return fail(RT_ERR_ARG, "rt_upload_optics_device: null pointer");
+    RT_HIP(hipSetDevice(c->device));
+    return pack_from_device(c, d_gas, d_cloud, d_ssa, d_asy);
+}
+
+int rt_set_scene(rt_context* c, float zenith_rad, float azimuth_rad, float albedo)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_set_scene: null context");
+    if (!(zenith_rad >= 0.0f) || !(zenith_rad < 1.5707963f))
+        return fail(RT_ERR_ARG, "rt_set_scene: zenith %g rad outside [0, pi/2)", zenith_rad);
+    if (!(albedo >= 0.0f) || !(albedo <= 1.0f))
+        return fail(RT_ERR_ARG, "rt_set_scene: albedo %g outside [0,1]", albedo);
+    c->zenith = zenith_rad; c->azimuth = azimuth_rad; c->albedo = albedo;
+    // raytracer_3d.cu:28-30, float arithmetic
+    c->slabs.sun[0] = -sinf(zenith_rad) * cosf(azimuth_rad);
+    c->slabs.sun[1] = -sinf(zenith_rad) * sinf(azimuth_rad);
+    c->slabs.sun[2] = -cosf(zenith_rad);
+    c->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_option(rt_context* c, const char* name, long long value)
+{
+    if (!c || !name) return fail(RT_ERR_ARG, "rt_set_option: null argument");
+    if (!strcmp(name, "fixed_dot")) c->fixed_dot = value != 0;
+    else if (!strcmp(name, "stats")) c->stats = value != 0;
+    else if (!strcmp(name, "blocks_per_cu"))
+    {
+        if (value < 1 || value > 16) return fail(RT_ERR_ARG, "rt_set_option: blocks_per_cu %lld outside [1,16]", value);
+        c->blocks_per_cu = (int)value;
+    }
+    else return fail(RT_ERR_ARG, "rt_set_option: unknown option \"%s\"", name);
+    return RT_OK;
+}
+
+int rt_set_stream(rt_context* c, void* hip_stream)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_set_stream: null context");
+    c->stream = (hipStream_t)hip_stream;
+    return RT_OK;
+}
+
+int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_trace: null context");
+    if (!c->have_optics || !c->have_scene)
+        return fail(RT_ERR_STATE, "rt_trace: call rt_upload_optics and rt_set_scene first");
+    if (pid_begin + count < pid_begin) return fail(RT_ERR_ARG, "rt_trace: photon id range overflows 64 bits");
+    RT_HIP(hipSetDevice(c->device));
+    if (count == 0) { c->timed = false; return RT_OK; }
+
+    TraceArgs a;
+    a.k_tot = c->d_k_tot; a.ssa = c->d_ssa; a.scat = c->d_scat;
+    a.tallies = c->d_tallies; a.events = c->d_events;
+    a.seed = seed; a.pid_begin = pid_begin; a.pid_end = pid_begin + count;
+    a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot;
+    a.ncol = (uint32_t)c->ncol; a.ncell = (uint32_t)c->ncell;
+    a.xs = (float)c->itot * c->dx; a.ys = (float)c->jtot * c->dy;
+    a.inv_xs = 1.0f / a.xs; a.inv_ys = 1.0f / a.ys;
+    a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
+    a.albedo = c->albedo;
+    a.sun_x = c->slabs.sun[0]; a.sun_y = c->slabs.sun[1]; a.sun_z = c->slabs.sun[2];
+    a.inv_sun_z = 1.0f / a.sun_z;
+    a.nslab = c->slabs.nslab;
+    for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
+    for (int i = 0; i < 3; ++i) a.inv_kmaj[i] = c->inv_kmaj[i];
+
+    uint64_t blocks = (count + kBlock - 1) / kBlock;
+    const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+
+    RT_HIP(hipEventRecord(c->ev_start, c->stream));
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    if (c->fixed_dot)
+    {
+        if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
+    }
+    else
+    {
+        if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+    }
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_context* c)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_synchronize: null context");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    unsigned long long aborted = 0;
+    RT_HIP(hipMemcpy(&aborted, c->d_events + RT_EV_ABORT, sizeof(aborted), hipMemcpyDeviceToHost));
+    if (aborted)
+        return fail(RT_ERR_ABORTED, "rt_synchronize: %llu photons abandoned by the step guard", aborted);
+    return RT_OK;
+}
+
+int rt_download_tallies(rt_context* c, uint64_t* const out[RT_N_TALLIES])
+{
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_download_tallies: null argument");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    size_t off = 0;
+    for (int t = 0; t < RT_N_TALLIES; ++t)
+    {
+        const size_t n = t < RT_ATMOS_DIRECT ? c->ncol : c->ncell;
+        if (!out[t]) return fail(RT_ERR_ARG, "rt_download_tallies: out[%d] is null", t);
+        RT_HIP(hipMemcpy(out[t], c->d_tallies + off, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        off += n;
+    }
+    return RT_OK;
+}
+
+int rt_upload_tallies(rt_context* c, const uint64_t* const in[RT_N_TALLIES])
+{
+    if (!c || !in) return fail(RT_ERR_ARG, "rt_upload_tallies: null argument");
+    RT_HIP(hipSetDevice(c->device));
+    unsigned long long* tmp = nullptr;
+    RT_HIP(hipMalloc(&tmp, c->nwords * sizeof(uint64_t)));
+    size_t off = 0;
+    for (int t = 0; t < RT_N_TALLIES; ++t)
+    {
+        const size_t n = t < RT_ATMOS_DIRECT ? c->ncol : c->ncell;
+        if (!in[t]) { (void)hipFree(tmp); return fail(RT_ERR_ARG, "rt_upload_tallies: in[%d] is null", t); }
+        hipError_t e = hipMemcpyAsync(tmp + off, in[t], n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RT_ERR_HIP, "rt_upload_tallies: %s", hipGetErrorString(e)); }
+        off += n;
+    }
+    hipLaunchKernelGGL(rt_add_u64_kernel, dim3(1024), dim3(256), 0, c->stream, c->d_tallies, tmp, c->nwords);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_upload_tallies: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_reset_tallies(rt_context* c)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_reset_tallies: null context");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipMemsetAsync(c->d_tallies, 0, c->nwords * sizeof(uint64_t), c->stream));
+    RT_HIP(hipMemsetAsync(c->d_events, 0, RT_N_EVENTS * sizeof(uint64_t), c->stream));
+    return RT_OK;
+}
+
+int rt_tally_device_buffer(rt_context* c, void** ptr, size_t* n_words)
+{
+    if (!c || !ptr || !n_words) return fail(RT_ERR_ARG, "rt_tally_device_buffer: null argument");
+    *ptr = c->d_tallies;
+    *n_words = c->nwords;
+    return RT_OK;
+}
+
+int rt_bind_tally_buffer(rt_context* c, void* ptr, size_t n_words)
+{
+    if (!c || !ptr) return fail(RT_ERR_ARG, "rt_bind_tally_buffer: null argument");
+    if (n_words != c->nwords)
+        return fail(RT_ERR_ARG, "rt_bind_tally_buffer: buffer has %zu words, the grid needs %zu", n_words, c->nwords);
+    if (((uintptr_t)ptr & 7u) != 0) return fail(RT_ERR_ARG, "rt_bind_tally_buffer: buffer not 8-byte aligned");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    if (c->owns_tallies && c->d_tallies) RT_HIP(hipFree(c->d_tallies));
+    c->d_tallies = (unsigned long long*)ptr;
+    c->owns_tallies = false;
+    return RT_OK;
+}
+
+int rt_get_slabs(rt_context* c, rt_slab_info* out)
+{
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_slabs: null argument");
+    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_slabs: call rt_upload_optics first");
+    *out = c->slabs;
+    return RT_OK;
+}
+
+int rt_get_events(rt_context* c, uint64_t out[RT_N_EVENTS])
+{
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_events: null argument");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    RT_HIP(hipMemcpy(out, c->d_events, RT_N_EVENTS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_last_trace_ms(rt_context* c, float* ms)
+{
+    if (!c || !ms) return fail(RT_ERR_ARG, "rt_last_trace_ms: null argument");
+    if (!c->timed) return fail(RT_ERR_STATE, "rt_last_trace_ms: no trace launched yet");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipEventSynchronize(c->ev_stop));
+    RT_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RT_OK;
+}
+
+int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint32_t key[2], uint32_t* out)
+{
+    if (!ctr || !key || !out) return fail(RT_ERR_ARG, "rt_selftest_philox: null argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(device_id));
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    RT_HIP(hipMalloc(&d_in, 16 * n));
+    RT_HIP(hipMalloc(&d_out, 16 * n));
+    RT_HIP(hipMemcpy(d_in, ctr, 16 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rt_selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, n, key[0], key[1], d_out);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpy(out, d_out, 16 * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return RT_OK;
+}
+
+int rt_selftest_math(int device_id, int which, const float* in, size_t n, float* out)
+{
+    if (!in || !out) return fail(RT_ERR_ARG, "rt_selftest_math: null argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(device_id));
+    float *d_in = nullptr, *d_out = nullptr;
+    RT_HIP(hipMalloc(&d_in, 4 * n));
+    RT_HIP(hipMalloc(&d_out, 4 * n));
+    RT_HIP(hipMemcpy(d_in, in, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rt_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, d_in, n, d_out);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpy(out, d_out, 4 * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,248 @@
+"""Host side of the MI355X photon tracer: a thin ctypes layer over librt_photon.so.
+
+Mirrors the host flow of the reference drivers (``run_ray_tracer`` in
+``/root/reference/src/raytracer_3d.cu:3-204`` and ``raytracer_3d_io.cu:3-213``): stage the grids,
+derive cloud bounds and majorants, launch the tracer, fetch the seven tally arrays, write them as
+``<name>.bin``. All compute happens in the HIP library; if the library is missing this module
+raises — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_photon.so")
+
+TALLY_NAMES = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up",
+               "atmos_direct", "atmos_diffuse")        # file names of raytracer_3d.cu:197-203
+EVENT_NAMES = ("steps", "collision_tests", "real", "scatter", "cloud_scatter", "surface", "toa",
+               "absorb", "transition", "abort")
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [("nslab", C.c_int), ("zface", C.c_float * 4), ("kmaj", C.c_float * 3),
+                ("k_lo", C.c_int), ("k_hi", C.c_int), ("cloud_min", C.c_float), ("cloud_max", C.c_float),
+                ("sun", C.c_float * 3)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load librt_photon.so (built in-tree by __graft_entry__.build()). Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, f32p, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+    sig = {
+        "rt_last_error": (C.c_char_p, []),
+        "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "rt_create": (C.c_int, [C.c_int] * 4 + [C.c_float] * 3 + [C.POINTER(vp)]),
+        "rt_destroy": (C.c_int, [vp]),
+        "rt_upload_optics": (C.c_int, [vp] + [f32p] * 4),
+        "rt_upload_optics_device": (C.c_int, [vp] * 5),
+        "rt_set_scene": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),
+        "rt_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
+        "rt_set_stream": (C.c_int, [vp, vp]),
+        "rt_trace": (C.c_int, [vp, u64, u64, u64]),
+        "rt_synchronize": (C.c_int, [vp]),
+        "rt_download_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
+        "rt_upload_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
+        "rt_reset_tallies": (C.c_int, [vp]),
+        "rt_tally_device_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
+        "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
+        "rt_get_events": (C.c_int, [vp, u64p]),
+        "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "rt_selftest_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "rt_selftest_math": (C.c_int, [C.c_int, C.c_int, f32p, C.c_size_t, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(f"[rt_status {rc}] " + load_library().rt_last_error().decode(errors="replace"))
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class PhotonTracer:
+    """One tracer context on one GPU (rt_context). Not thread-safe; one per GPU."""
+
+    def __init__(self, itot, jtot, ktot, dx, dy, dz, device=0):
+        self.lib = load_library()
+        self.itot, self.jtot, self.ktot = int(itot), int(jtot), int(ktot)
+        self.dx, self.dy, self.dz = float(dx), float(dy), float(dz)
+        self.ncol = self.itot * self.jtot
+        self.ncell = self.ncol * self.ktot
+        self.nwords = 5 * self.ncol + 2 * self.ncell
+        self.device = device
+        h = C.c_void_p()
+        _check(self.lib.rt_create(device, self.itot, self.jtot, self.ktot, self.dx, self.dy, self.dz, C.byref(h)))
+        self._h = h
+        self._bound = None
+
+    @classmethod
+    def from_scene(cls, scene, device=0, **options):
+        t = cls(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz, device=device)
+        t.upload_optics(*scene.fields())
+        t.set_scene(scene.zenith_deg, scene.azimuth_deg, scene.albedo)
+        for k, v in options.items():
+            t.set_option(k, v)
+        return t
+
+    # -- staging ---------------------------------------------------------------------------
+    def upload_optics(self, k_gas, k_cloud, ssa, asy):
+        arrs = []
+        for name, a in (("k_ext_gas", k_gas), ("k_ext_cloud", k_cloud), ("ssa", ssa), ("asy", asy)):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.size != self.ncell:
+                raise RtError(f"{name}: {a.size} values, the grid has {self.ncell}")
+            arrs.append(a)
+        _check(self.lib.rt_upload_optics(self._h, *[_f32p(a) for a in arrs]))
+
+    def upload_optics_device(self, d_gas, d_cloud, d_ssa, d_asy):
+        """Device pointers (ints) of four float32 arrays already on this GPU."""
+        _check(self.lib.rt_upload_optics_device(self._h, *[C.c_void_p(int(p)) for p in (d_gas, d_cloud, d_ssa, d_asy)]))
+
+    def set_scene(self, zenith_deg=50.0, azimuth_deg=20.0, albedo=0.2):
+        f = np.float32
+        # angles become floats before the cosines are taken, raytracer_3d.cu:25-26
+        _check(self.lib.rt_set_scene(self._h, f(zenith_deg * (math.pi / 180.0)), f(azimuth_deg * (math.pi / 180.0)), f(albedo)))
+
+    def set_option(self, name, value):
+        _check(self.lib.rt_set_option(self._h, name.encode(), int(value)))
+
+    def set_stream(self, hip_stream_ptr):
+        _check(self.lib.rt_set_stream(self._h, C.c_void_p(int(hip_stream_ptr) if hip_stream_ptr else None)))
+
+    def bind_tally_tensor(self, tensor):
+        """Accumulate into a caller-owned int64 device tensor of nwords elements (for collectives)."""
+        if tensor.numel() != self.nwords or tensor.element_size() != 8 or not tensor.is_contiguous():
+            raise RtError(f"tally tensor must be contiguous, 8-byte, {self.nwords} elements")
+        _check(self.lib.rt_bind_tally_buffer(self._h, C.c_void_p(tensor.data_ptr()), self.nwords))
+        self._bound = tensor
+
+    # -- the hot path -----------------------------------------------------------------------
+    def trace(self, seed, photon_id_begin, photon_count):
+        _check(self.lib.rt_trace(self._h, int(seed), int(photon_id_begin), int(photon_count)))
+
+    def synchronize(self):
+        _check(self.lib.rt_synchronize(self._h))
+
+    def reset(self):
+        _check(self.lib.rt_reset_tallies(self._h))
+
+    def last_trace_ms(self):
+        ms = C.c_float()
+        _check(self.lib.rt_last_trace_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- results ----------------------------------------------------------------------------
+    def _host_tallies(self):
+        out = {}
+        for n in TALLY_NAMES:
+            shape = (self.ktot, self.jtot, self.itot) if n.startswith("atmos") else (self.jtot, self.itot)
+            out[n] = np.zeros(shape, dtype=np.uint64)
+        return out
+
+    def tallies(self):
+        out = self._host_tallies()
+        ptrs = (C.POINTER(C.c_uint64) * 7)(*[out[n].ctypes.data_as(C.POINTER(C.c_uint64)) for n in TALLY_NAMES])
+        _check(self.lib.rt_download_tallies(self._h, ptrs))
+        return out
+
+    def add_tallies(self, tallies):
+        arrs = [np.ascontiguousarray(tallies[n], dtype=np.uint64) for n in TALLY_NAMES]
+        ptrs = (C.POINTER(C.c_uint64) * 7)(*[a.ctypes.data_as(C.POINTER(C.c_uint64)) for a in arrs])
+        _check(self.lib.rt_upload_tallies(self._h, ptrs))
+
+    def events(self):
+        ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
+        _check(self.lib.rt_get_events(self._h, ev.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return dict(zip(EVENT_NAMES, (int(v) for v in ev)))
+
+    def slabs(self):
+        s = SlabInfo()
+        _check(self.lib.rt_get_slabs(self._h, C.byref(s)))
+        return s
+
+    def tally_device_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.rt_tally_device_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def split_tally_words(words, itot, jtot, ktot):
+    """Concatenated tally buffer (host array of nwords) -> dict of the seven arrays."""
+    ncol, ncell = itot * jtot, itot * jtot * ktot
+    out, off = {}, 0
+    for n in TALLY_NAMES:
+        if n.startswith("atmos"):
+            out[n] = np.asarray(words[off:off + ncell]).view(np.uint64).reshape(ktot, jtot, itot)
+            off += ncell
+        else:
+            out[n] = np.asarray(words[off:off + ncol]).view(np.uint64).reshape(jtot, itot)
+            off += ncol
+    return out
+
+
+def save_tallies(tallies, directory="."):
+    """Write the seven ``<name>.bin`` files of raytracer_3d.cu:184-203 (uint64, truncating)."""
+    os.makedirs(directory, exist_ok=True)
+    for n in TALLY_NAMES:
+        path = os.path.join(directory, n + ".bin")
+        try:
+            np.ascontiguousarray(tallies[n], dtype=np.uint64).tofile(path)
+        except OSError as exc:
+            raise RuntimeError(f'Cannot write file "{n}.bin"') from exc
+
+
+def photon_balance(t) -> int:
+    """balance_in - balance_out of plot_results_3d.py:41-44; exactly 0 for a complete run."""
+    inn = int(t["toa_down"].sum())
+    out = int(t["surface_down_direct"].sum()) + int(t["surface_down_diffuse"].sum()) - int(t["surface_up"].sum()) \
+        + int(t["toa_up"].sum()) + int(t["atmos_direct"].sum()) + int(t["atmos_diffuse"].sum())
+    return inn - out
+
+
+def algorithmic_bytes(events, n_photons) -> int:
+    """4 B per collision test (k_tot) + 4 B per real collision (ssa) + 8 B per
+    scattering ({asy, k_cloud}) + 16 B (8-byte read-modify-write) per tally update: one launch
+    tally per photon plus one per surface arrival, surface reflection (= surface arrivals that
+    did not end the photon), TOA escape and absorption."""
+    e = events
+    reflections = e["surface"] - (n_photons - e["toa"] - e["absorb"])
+    tally_updates = n_photons + e["surface"] + reflections + e["toa"] + e["absorb"]
+    return 4 * e["collision_tests"] + 4 * e["real"] + 8 * e["scatter"] + 16 * tally_updates

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Tallies are integer counts, so the bar is exact equality of all seven arrays on the same seeded
+photon-ID range. Sizes are what oracle/photon_oracle.c finishes in seconds.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    raytracer_amd.load_library()
+    return raytracer_amd
+
+
+def _assert_same(got, want):
+    for name in O.TALLY_NAMES:
+        assert got[name].shape == want[name].shape
+        diff = np.flatnonzero(got[name].ravel() != want[name].ravel())
+        assert diff.size == 0, f"{name}: {diff.size} cells differ (first at {diff[:5]})"
+
+
+def test_philox_device_matches_known_answers_and_oracle(rt):
+    lib = rt.load_library()
+    kat = [([0] * 4, [0] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        c = np.array(ctr, dtype=np.uint32); k = np.array(key, dtype=np.uint32); o = np.zeros(4, dtype=np.uint32)
+        rc = lib.rt_selftest_philox(0, c.ctypes.data_as(C.POINTER(C.c_uint32)), 1,
+                                    k.ctypes.data_as(C.POINTER(C.c_uint32)), o.ctypes.data_as(C.POINTER(C.c_uint32)))
+        assert rc == 0, lib.rt_last_error()
+        assert [int(v) for v in o] == want
+    rng = np.random.default_rng(0)
+    n = 4096
+    ctr = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    key = np.array([0x12345678, 0x9abcdef0], dtype=np.uint32)
+    out = np.zeros((n, 4), dtype=np.uint32)
+    assert lib.rt_selftest_philox(0, ctr.ctypes.data_as(C.POINTER(C.c_uint32)), n,
+                                  key.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    ol = O.lib()
+    for r in range(0, n, 97):
+        w = (C.c_uint32 * 4)()
+        ol.oracle_philox4x32_10((C.c_uint32 * 4)(*ctr[r]), (C.c_uint32 * 2)(*key), w)
+        assert list(w) == [int(v) for v in out[r]]
+
+
+def test_device_math_is_bit_identical_to_oracle(rt):
+    lib = rt.load_library()
+    ol = O.lib()
+    lattice = (np.arange(0, 1 << 24, 257, dtype=np.uint32)).astype(np.float32) * np.float32(2.0 ** -24)
+    cases = {0: (np.float32(1.0) - lattice) + np.float32(1.1920928955078125e-07),   # the argument of the log
+             1: np.linspace(0.2, 4.3, 50001, dtype=np.float32),                      # cube-root range
+             2: lattice, 3: lattice}
+    for which, x in cases.items():
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        got = np.zeros_like(x)
+        assert lib.rt_selftest_math(0, which, x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
+                                    got.ctypes.data_as(C.POINTER(C.c_float))) == 0, lib.rt_last_error()
+        want = np.zeros_like(x)
+        s, c = C.c_float(), C.c_float()
+        for i, v in enumerate(x):
+            if which == 0:
+                want[i] = ol.oracle_logf(float(v))
+            elif which == 1:
+                want[i] = ol.oracle_cbrtf(float(v))
+            else:
+                ol.oracle_sincos2pi(float(v), C.byref(s), C.byref(c))
+                want[i] = s.value if which == 2 else c.value
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"math fn {which}"
+    # accuracy against libm in double, so the parity is not bit-exact agreement on a wrong function
+    x = cases[0].astype(np.float64)
+    got = np.zeros(x.size, dtype=np.float32)
+    xin = cases[0]
+    lib.rt_selftest_math(0, 0, xin.ctypes.data_as(C.POINTER(C.c_float)), xin.size, got.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.max(np.abs(got - np.log(x))) < 2e-6
+
+
+@pytest.mark.parametrize("scene_name,n", [("tiny", 1 << 16), ("block_cloud", 1 << 19), ("rayleigh", 1 << 18),
+                                          ("rayleigh_absorbing", 1 << 18), ("cumulus_small", 1 << 18),
+                                          ("cloud_to_ground", 1 << 16), ("cloud_to_top", 1 << 16)])
+def test_tallies_bit_identical_to_oracle(rt, scene_name, n):
+    S = rt.scenes
+    scene = {
+        "tiny": lambda: S.tiny(),
+        "block_cloud": lambda: S.block_cloud(),
+        "rayleigh": lambda: S.rayleigh_column(ssa=1.0),
+        "rayleigh_absorbing": lambda: S.rayleigh_column(ssa=0.5, scale_height=8000.0),
+        "cumulus_small": lambda: S.cumulus(96, 80, 48, 50.0, 50.0, 25.0, n_clouds=12, seed=3, z_base=300.0, z_top=900.0),
+        "cloud_to_ground": lambda: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=5, z_base=0.0, z_top=300.0),
+        "cloud_to_top": lambda: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=6, z_base=300.0, z_top=600.0),
+    }[scene_name]()
+    tr = rt.PhotonTracer.from_scene(scene, stats=1)
+    sl, osl = tr.slabs(), O.oracle_slabs(scene)
+    assert sl.nslab == osl.nslab and list(sl.zface) == list(osl.zface) and list(sl.kmaj) == list(osl.kmaj)
+    assert (sl.k_lo, sl.k_hi) == (osl.k_lo, osl.k_hi) and list(sl.sun) == list(osl.sun)
+    seed, begin = 1234, 10_000_000_000      # photon IDs beyond 2^32 exercise the high counter word
+    tr.trace(seed, begin, n)
+    tr.synchronize()
+    got = tr.tallies()
+    want, ev = O.photon_oracle(scene, seed, begin, n)
+    _assert_same(got, want)
+    assert rt.photon_balance(got) == 0
+    assert int(got["toa_down"].sum()) == n
+    gev = tr.events()
+    assert gev == ev
+    tr.close()
+
+
+def test_fixed_dot_mode_matches_oracle(rt):
+    scene = rt.scenes.tiny()
+    tr = rt.PhotonTracer.from_scene(scene, fixed_dot=1)
+    tr.trace(5, 0, 1 << 16)
+    tr.synchronize()
+    want, _ = O.photon_oracle(scene, 5, 0, 1 << 16, fixed_dot=True)
+    _assert_same(tr.tallies(), want)
+    compat, _ = O.photon_oracle(scene, 5, 0, 1 << 16, fixed_dot=False)
+    assert any(not np.array_equal(compat[n], want[n]) for n in O.TALLY_NAMES)
+
+
+def test_split_ranges_and_launch_shapes_give_identical_tallies(rt):
+    """Reproducibility at any GPU count: the sum over disjoint photon-ID ranges equals one call."""
+    scene = rt.scenes.tiny()
+    n = 1 << 17
+    ref = rt.PhotonTracer.from_scene(scene)
+    ref.trace(9, 0, n); ref.synchronize()
+    whole = ref.tallies()
+    for parts, bpc in ((2, 1), (8, 3), (5, 8)):
+        tr = rt.PhotonTracer.from_scene(scene, blocks_per_cu=bpc)
+        edges = np.linspace(0, n, parts + 1).astype(np.int64)
+        for a, b in zip(edges[:-1], edges[1:]):
+            tr.trace(9, int(a), int(b - a))
+        tr.synchronize()
+        _assert_same(tr.tallies(), whole)
+        tr.close()
+
+
+def test_empty_and_single_photon_and_accumulate(rt):
+    scene = rt.scenes.tiny()
+    tr = rt.PhotonTracer.from_scene(scene)
+    tr.trace(1, 0, 0); tr.synchronize()
+    assert all(int(v.sum()) == 0 for v in tr.tallies().values())
+    tr.trace(1, 77, 1); tr.synchronize()
+    want, _ = O.photon_oracle(scene, 1, 77, 1)
+    _assert_same(tr.tallies(), want)
+    # accumulate on top of uploaded counts (restart path), then reset
+    tr.add_tallies(want)
+    got = tr.tallies()
+    for name in O.TALLY_NAMES:
+        assert np.array_equal(got[name], 2 * want[name])
+    tr.reset(); tr.synchronize()
+    assert all(int(v.sum()) == 0 for v in tr.tallies().values())
+
+
+def test_errors_are_reported_not_fatal(rt):
+    with pytest.raises(rt.RtError):
+        rt.PhotonTracer(0, 4, 4, 1.0, 1.0, 1.0)
+    tr = rt.PhotonTracer(4, 4, 4, 1.0, 1.0, 1.0)
+    with pytest.raises(rt.RtError):
+        tr.trace(0, 0, 10)              # optics not uploaded
+    with pytest.raises(rt.RtError):
+        tr.upload_optics(*[np.zeros(5, dtype=np.float32)] * 4)
+    with pytest.raises(rt.RtError):
+        tr.set_option("no_such_option", 1)
+    with pytest.raises(rt.RtError):
+        tr.set_scene(zenith_deg=95.0)
+
+
+def test_full_size_properties_block_cloud(rt):
+    """2^24 photons on the reference's own scene: exact balance, exact launch count, global
+    fractions within 4 sigma of the golden table of the compiled reference."""
+    scene = rt.scenes.block_cloud()
+    n = 1 << 24
+    tr = rt.PhotonTracer.from_scene(scene)
+    tr.trace(2024, 0, n); tr.synchronize()
+    t = tr.tallies()
+    assert rt.photon_balance(t) == 0
+    assert int(t["toa_down"].sum()) == n
+    golden_n = 10_000_805
+    golden = {"toa_up": 1_699_943, "surface_down_direct": 5_878_188, "surface_down_diffuse": 977_326,
+              "surface_up": 1_369_827, "atmos_direct": 1_961_730, "atmos_diffuse": 853_445}
+    for name, cnt in golden.items():
+        p_ref = cnt / golden_n
+        p = int(t[name].sum()) / n
+        sigma = np.sqrt(p_ref * (1 - p_ref) * (1 / n + 1 / golden_n))
+        assert abs(p - p_ref) < 4 * sigma, f"{name}: {p} vs {p_ref} ({(p - p_ref) / sigma:.2f} sigma)"
