@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — photons/sec of the MI355X photon tracer on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W                 # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W     # one rank per GPU (RCCL)
+
+A "step" is one complete job on the workload's grid: zero the tallies, trace this rank's batch of
+photons (IDs keyed by step and rank, so every photon of the run is distinct), and — for N > 1 —
+sum the tallies over ranks with ONE all-reduce (RCCL over xGMI; the path's only exchange step,
+SURVEY.md §8e). Work per GPU is fixed as N grows (weak scaling). Inputs are resident in HBM before
+the timed region (grids uploaded and packed once).
+
+Prints ONE JSON line on rank 0 (metric of BASELINE.json: photons/sec, whole node) carrying
+  roofline      algorithmic bytes per launch (from the kernel's own event counters, SURVEY.md
+                §8d formula) / average kernel time measured with events on the launch stream
+  cpu_baseline  oracle/cpu_ref.cpp (restatement of the reference's raytracer_3d.cpp, bit-pinned
+                to it) timed on this host on a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (scene factory name, default log2 photons per GPU per step, description)
+    "c1": ("block_cloud", 26, "C1 block cloud 128x128x128 (raytracer_3d.cu built-in scene)"),
+    "c2": ("rayleigh_column", 24, "C2 clear-sky Rayleigh column 64x64x64"),
+    "c3": ("cumulus_c3", 26, "C3 broken cumulus 256x256x128, HG cloud + Lambertian surface"),
+    "c4": ("cumulus_c4", 27, "C4 LES cumulus 1024x1024x128 (2^30 photons over 8 GPUs)"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_GLANEOPS = 78643.2   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane per clock
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--photons-log2", type=int, default=None, help="photons per GPU per step (log2)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU sample")
+    ap.add_argument("--blocks-per-cu", type=int, default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, seconds):
+    """Time oracle/cpu_ref.cpp (the checker, here only as the reported CPU baseline) on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
+    s64 = O.scene_to_f64(scene)
+    probe = 200_000
+    t0 = time.perf_counter()
+    t, _ = O.cpu_ref(s64, probe, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rate = int(t["toa_down"].sum()) / dt
+    n = int(max(probe, min(rate * seconds, 5e8)))
+    t0 = time.perf_counter()
+    t, _ = O.cpu_ref(s64, n, nthreads=cores)
+    dt = time.perf_counter() - t0
+    traced = int(t["toa_down"].sum())
+    return {"value": traced / dt, "unit": "photons/s", "cores": cores, "kind": "port",
+            "sample": f"{traced} photons of the same scene through oracle/cpu_ref.cpp "
+                      f"(double, xoroshiro128+, global majorant; bit-pinned to raytracer_3d.cpp) in {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    factory, default_log2, desc = WORKLOADS[args.workload]
+    log2n = args.photons_log2 if args.photons_log2 is not None else default_log2
+    n_per_gpu = 1 << log2n
+    scene = getattr(rt.scenes, factory)()
+
+    tr = rt.PhotonTracer.from_scene(scene, device=local_rank)
+    if args.blocks_per_cu:
+        tr.set_option("blocks_per_cu", args.blocks_per_cu)
+    stream = torch.cuda.current_stream()
+    tr.set_stream(stream.cuda_stream)
+    tally = torch.zeros(tr.nwords, dtype=torch.int64, device=dev)   # uint64 bit patterns; sums wrap alike
+    tr.bind_tally_tensor(tally)
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(idx, timed_slot=None):
+        tr.reset()
+        begin = (idx * world + rank) * n_per_gpu
+        if timed_slot is not None:
+            starts[timed_slot].record(stream)
+        tr.trace(args.seed, begin, n_per_gpu)
+        if timed_slot is not None:
+            stops[timed_slot].record(stream)
+        if world > 1:
+            dist.all_reduce(tally, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, timed_slot=k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    tr.synchronize()    # raises if any photon was abandoned by the step guard
+
+    kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+
+    # sanity on the last step's result (after the all-reduce every rank holds the node total)
+    words = tally.cpu().numpy()
+    t = rt.split_tally_words(words, scene.itot, scene.jtot, scene.ktot)
+    launched = int(t["toa_down"].sum())
+    balance = rt.photon_balance(t)
+    if balance != 0 or launched != n_per_gpu * world:
+        raise SystemExit(f"bench: invalid result (balance {balance}, launched {launched}, expected {n_per_gpu * world})")
+
+    out = None
+    if rank == 0:
+        # event counters of exactly one launch (same photon range as the last timed step of rank 0)
+        tr.set_option("stats", 1)
+        tr.reset()
+        tr.trace(args.seed, ((args.warmup + args.steps - 1) * world) * n_per_gpu, n_per_gpu)
+        tr.synchronize()
+        ev = tr.events()
+        tr.set_option("stats", 0)
+        alg_bytes = rt.algorithmic_bytes(ev, n_per_gpu)
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        total_photons = n_per_gpu * world * args.steps
+        value = total_photons / elapsed
+        out = {
+            "metric": "photons/sec (whole node)", "value": value, "unit": "photons/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{desc}; 2^{log2n} photons per GPU per step; "
+                                   f"grid {scene.itot}x{scene.jtot}x{scene.ktot}; zenith {scene.zenith_deg} deg, "
+                                   f"albedo {scene.albedo}; step = reset + trace" + (" + RCCL all-reduce of tallies" if world > 1 else ""),
+                       "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rt_trace_kernel", "kernel_ms": avg_kernel_ms,
+                         "algorithmic_bytes_per_photon": alg_bytes / n_per_gpu,
+                         "events_per_photon": {k: v / n_per_gpu for k, v in ev.items()}},
+            "kernel_photons_per_s_per_gpu": n_per_gpu / (avg_kernel_ms * 1e-3),
+        }
+        prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+        if os.path.exists(prof):
+            try:
+                with open(prof) as fh:
+                    p = json.load(fh)
+                if p.get("photons_per_launch") == n_per_gpu:
+                    out["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)
+    tr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

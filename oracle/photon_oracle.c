@@ -169,6 +169,10 @@ static inline float henyey_mu(float g, float r)
     return -(a / b) - c;
 }
 
+/* exported for the sampler-moment tests */
+float oracle_rayleigh_mu(float r) { return rayleigh_mu(r); }
+float oracle_henyey_mu(float g, float r) { return henyey_mu(g, r); }
+
 /* raytracer_kernels.cu:165-170 */
 static inline float free_path_tau(float r) { return -oracle_logf((1.0f - r) + RT_EPS); }
 
@@ -386,7 +390,10 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                 const int from_cloud = u01(v[0]) < k_cloud[c] / kt;
                 if (from_cloud) ++ev[EV_CSCAT];
                 const float mu = from_cloud ? henyey_mu(asy[c], u01(v[1])) : rayleigh_mu(u01(v[1]));
-                const float sn = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
+                /* raytracer_kernels.cu:523. In float the inverse CDFs can return |mu| a few ulp
+                 * above 1, which makes the radicand negative (NaN direction in the reference);
+                 * clamped at 0 here (SURVEY.md §7 "float edge cases"). */
+                const float sn = sqrtf(fmaxf(fmaf(-mu, mu, 1.0f) + RT_EPS, 0.0f));
 
                 /* frame, raytracer_kernels.cu:525-541 */
                 float ax = 0.0f, ay = 0.0f, az = 0.0f;

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (written by profiles/run_rocprof.sh) into
+profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and profiles/<tag>_pmc.json
+(per-launch counter values of rt_trace_kernel), and refresh profiles/pmc_<workload>.json that
+bench.py reads for roofline.traffic.
+
+HBM traffic per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 bytes (rocprofv3 reports KiB).
+MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports WIDE COALESCED streaming reads by 2x on gfx950
+and is uncalibrated for other widths. This kernel's reads are 4/8-byte random gathers; calibration
+on its own pattern: TCC_MISS_sum * 64 B agrees with FETCH_SIZE * 1024 (one 64-B request per gather
+miss), so no doubling is applied here."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag, workload, photons = sys.argv[1], sys.argv[2], int(sys.argv[3])
+src = f"gpurun_out/prof_{tag}"
+here = os.path.dirname(os.path.abspath(__file__))
+shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"{here}/{tag}_kernel_stats.csv")
+pmc = {}
+for d in sorted(glob.glob(f"{src}/pmc_*/")):
+    for f in glob.glob(d + "*/*_counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "rt_trace_kernel<false, false>" in r["Kernel_Name"] or "rt_trace_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                pmc["vgpr"] = int(r["VGPR_Count"]); pmc["sgpr"] = int(r["SGPR_Count"]); pmc["grid"] = int(r["Grid_Size"])
+        for k, v in agg.items():
+            pmc[k] = sum(v) / len(v)
+stats = [r for r in csv.DictReader(open(f"{here}/{tag}_kernel_stats.csv")) if "rt_trace_kernel" in r["Name"] and "true>" not in r["Name"]]
+pmc["kernel_avg_ns"] = float(stats[0]["AverageNs"]); pmc["kernel_calls"] = int(stats[0]["Calls"])
+pmc["photons_per_launch"] = photons
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    pmc["hbm_bytes_per_launch"] = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024
+if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_INSTS_VALU" in pmc:
+    pmc["active_lanes_per_valu_inst"] = pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"]
+    pmc["valu_wave_insts_per_photon"] = pmc["SQ_INSTS_VALU"] / photons
+json.dump(pmc, open(f"{here}/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
+json.dump({"photons_per_launch": photons, "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "source": f"profiles/{tag}_pmc.json"},
+          open(f"{here}/pmc_{workload}.json", "w"), indent=1)
+print(json.dumps(pmc, indent=1, sort_keys=True))

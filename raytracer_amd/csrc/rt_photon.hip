@@ -211,7 +211,9 @@ rt_trace_kernel(const TraceArgs a)
                 const bool from_cloud = u01(v.x) < ak.y / kt;
                 if (STATS && from_cloud) ++ev_cscat;
                 const float mu = from_cloud ? henyey_mu(ak.x, u01(v.y)) : rayleigh_mu(u01(v.y));
-                const float sn = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+                // |mu| can come out a few ulp above 1 in float: clamp the radicand (the reference
+                // would produce a NaN direction here, raytracer_kernels.cu:523)
+                const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
 
                 // frame, raytracer_kernels.cu:525-541
                 float ax = 0.0f, ay = 0.0f, az = 0.0f;

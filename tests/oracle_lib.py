@@ -65,6 +65,10 @@ def lib():
         _lib.oracle_logf.argtypes = [C.c_float]
         _lib.oracle_cbrtf.restype = C.c_float
         _lib.oracle_cbrtf.argtypes = [C.c_float]
+        _lib.oracle_rayleigh_mu.restype = C.c_float
+        _lib.oracle_rayleigh_mu.argtypes = [C.c_float]
+        _lib.oracle_henyey_mu.restype = C.c_float
+        _lib.oracle_henyey_mu.argtypes = [C.c_float, C.c_float]
         _lib.oracle_sincos2pi.restype = None
         _lib.oracle_sincos2pi.argtypes = [C.c_float, f32p, f32p]
     return _lib

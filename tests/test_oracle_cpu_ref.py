@@ -1,0 +1,64 @@
+"""Pins oracle/cpu_ref.cpp (restatement of the reference CPU tracer) to the reference itself:
+bit-exact against golden digests of the compiled reference, and against the compiled reference
+run live when oracle/_ref exists (build container)."""
+import hashlib
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def run_100k():
+    return O.cpu_ref(O.block_cloud_f64(), 100000, nthreads=1)[0]
+
+
+def test_bit_exact_against_golden_digests_of_compiled_reference(run_100k):
+    gold = json.load(open(os.path.join(GOLD, "cpu_ref_100k.json")))
+    for n in O.TALLY_NAMES:
+        assert int(run_100k[n].sum()) == gold[n]["sum"], n
+        assert hashlib.md5(run_100k[n].tobytes()).hexdigest() == gold[n]["md5"], n
+    assert O.balance(run_100k) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_BIN), reason="compiled reference (oracle/_ref) not built here")
+def test_bit_exact_against_compiled_reference_live(run_100k):
+    with tempfile.TemporaryDirectory() as d:
+        ref = O.run_reference_binary(1, d, nthreads=1)
+    for n in O.TALLY_NAMES:
+        assert np.array_equal(ref[n], run_100k[n]), n
+
+
+def test_statistics_against_reference_at_1e7():
+    """Multi-threaded run (different streams than the golden run): fractions within 4 sigma,
+    per-level absorption profile chi-square consistent."""
+    gold = json.load(open(os.path.join(GOLD, "reference_1e7.json")))
+    t, _ = O.cpu_ref(O.block_cloud_f64(), 4_000_000, nthreads=0)
+    assert O.balance(t) == 0
+    n, ng = int(t["toa_down"].sum()), gold["sums"]["toa_down"]
+    for name in O.TALLY_NAMES[1:]:
+        p, pg = int(t[name].sum()) / n, gold["sums"][name] / ng
+        sig = np.sqrt(pg * (1 - pg) * (1 / n + 1 / ng))
+        assert abs(p - pg) < 4 * sig, (name, p, pg)
+    lev = (t["atmos_direct"] + t["atmos_diffuse"]).sum(axis=(1, 2)).astype(np.float64)
+    levg = np.array(gold["atmos_level_sums"], dtype=np.float64)
+    z = (lev / n - levg / ng) / np.sqrt(levg / ng * (1 / n + 1 / ng))
+    assert np.max(np.abs(z)) < 5 and 0.6 < np.mean(z ** 2) < 1.6
+    # SURVEY.md §8c golden per-level values of the reference
+    assert [int(levg[k]) for k in (0, 40, 50, 59, 60, 127)] == [17967, 23575, 25098, 26356, 20991, 23869]
+
+
+def test_generalised_fields_equal_builtin_scene():
+    """The float32 product scene widened to double gives the same majorant and statistically the
+    same answer as the double scene (sanity of scene_to_f64, used by the CPU baseline)."""
+    from raytracer_amd import scenes
+    t, _ = O.cpu_ref(O.scene_to_f64(scenes.block_cloud()), 300000, nthreads=0)
+    assert O.balance(t) == 0
+    p = int(t["surface_down_direct"].sum()) / int(t["toa_down"].sum())
+    assert abs(p - 0.5878) < 0.005
