@@ -1,0 +1,207 @@
+// driver_common.h — shared host code of the two drop-in executables.
+//
+// They replace the reference's host drivers (run_ray_tracer + main of src/raytracer_3d.cu:3-227 and
+// src/raytracer_3d_io.cu:3-236): same positional argument (photon count = 2^n), same stdout lines,
+// same input and output files in the working directory. All device work goes through the C ABI of
+// include/rt_photon.h. Optional --key=value arguments replace the reference's compile-time literals
+// (its defaults are kept).
+#pragma once
+
+#include "../include/rt_photon.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace drv
+{
+struct Config
+{
+    int itot, jtot, ktot;
+    float dx, dy, dz;
+    float albedo = 0.2f;                      // raytracer_3d.cu:24
+    std::vector<double> zenith_deg{50.};      // raytracer_3d.cu:25 (a list = resident-grid sweep)
+    double azimuth_deg = 20.;                 // raytracer_3d.cu:26
+    uint64_t seed = 0;
+    int ngpus = 1;
+    std::string indir = ".", outdir = ".";
+    int exponent = -1;
+    bool fixed_dot = false;
+};
+
+inline void die(const std::string& msg)
+{
+    std::cerr << msg << std::endl;
+    std::exit(1);
+}
+
+inline void check(int rc, const char* what)
+{
+    if (rc != RT_OK)
+        die(std::string(what) + ": " + rt_last_error());
+}
+
+// argv: exactly one positional (the exponent n, raytracer_3d.cu:209-215) plus --key=value options.
+inline void parse_args(int argc, char** argv, Config& c)
+{
+    int positional = 0;
+    for (int i = 1; i < argc; ++i)
+    {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) == 0)
+        {
+            const size_t eq = a.find('=');
+            const std::string key = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            const std::string val = eq == std::string::npos ? "1" : a.substr(eq + 1);
+            if (key == "itot") c.itot = std::stoi(val);
+            else if (key == "jtot") c.jtot = std::stoi(val);
+            else if (key == "ktot") c.ktot = std::stoi(val);
+            else if (key == "dx") c.dx = std::stof(val);
+            else if (key == "dy") c.dy = std::stof(val);
+            else if (key == "dz") c.dz = std::stof(val);
+            else if (key == "albedo") c.albedo = std::stof(val);
+            else if (key == "azimuth") c.azimuth_deg = std::stod(val);
+            else if (key == "seed") c.seed = std::stoull(val);
+            else if (key == "ngpus") c.ngpus = std::stoi(val);
+            else if (key == "indir") c.indir = val;
+            else if (key == "outdir") c.outdir = val;
+            else if (key == "physics") c.fixed_dot = (val == "fixed");
+            else if (key == "zenith")
+            {
+                c.zenith_deg.clear();
+                std::stringstream ss(val);
+                std::string item;
+                while (std::getline(ss, item, ',')) c.zenith_deg.push_back(std::stod(item));
+                if (c.zenith_deg.empty()) die("--zenith needs at least one angle");
+            }
+            else die("Unknown option --" + key);
+        }
+        else
+        {
+            ++positional;
+            c.exponent = std::stoi(a);
+        }
+    }
+    if (positional != 1)
+    {
+        // message and exit status of raytracer_3d.cu:209-213
+        std::cout << "The number of photons is must be a power of two (2**n), please add the exponent n" << std::endl;
+        std::exit(1);
+    }
+    if (c.exponent < 0 || c.exponent > 62) die("The exponent n must be in [0, 62]");
+}
+
+inline void save_binary(const std::string& dir, const std::string& name, const void* ptr, size_t count)
+{
+    // raytracer_3d.cu:184-195
+    std::ofstream f(dir + "/" + name + ".bin", std::ios::out | std::ios::trunc | std::ios::binary);
+    if (!f) throw std::runtime_error("Cannot write file \"" + name + ".bin\"");
+    f.write(reinterpret_cast<const char*>(ptr), count * sizeof(uint64_t));
+}
+
+inline void load_binary(const std::string& dir, const std::string& name, float* ptr, size_t count)
+{
+    // raytracer_3d_io.cu:36-47, reading exactly count float32 (the reference asks for twice as
+    // many bytes and relies on the short read, :41)
+    std::ifstream f(dir + "/" + name + ".bin", std::ios::in | std::ios::binary);
+    if (!f) throw std::runtime_error("Cannot read file \"" + name + ".bin\"");
+    f.read(reinterpret_cast<char*>(ptr), count * sizeof(float));
+    if (static_cast<size_t>(f.gcount()) != count * sizeof(float))
+        throw std::runtime_error("File \"" + name + ".bin\" is shorter than itot*jtot*ktot float32 values");
+}
+
+static const char* const kTallyNames[RT_N_TALLIES] = {
+    "toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up", "atmos_direct", "atmos_diffuse"};
+
+// The body of run_ray_tracer after the fields exist (raytracer_3d.cu:72-203).
+inline void run(const Config& c, const std::vector<float>& k_gas, const std::vector<float>& k_cloud,
+                const std::vector<float>& ssa, const std::vector<float>& asy)
+{
+    const uint64_t n_photons = 1ull << c.exponent;
+    int ndev = 0;
+    check(rt_device_count(&ndev), "rt_device_count");
+    if (c.ngpus < 1 || c.ngpus > ndev) die("--ngpus must be between 1 and the number of visible GPUs");
+    // first line of the reference (raytracer_3d.cu:7): its launch was 64 x 512 threads
+    std::cout << "Shooting " << n_photons << " photons (" << n_photons / (64 * 512) << " per thread) " << std::endl;
+
+    const size_t ncol = (size_t)c.itot * c.jtot, ncell = ncol * c.ktot;
+    std::vector<rt_context*> ctx(c.ngpus, nullptr);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    for (int g = 0; g < c.ngpus; ++g)
+    {
+        check(rt_create(g, c.itot, c.jtot, c.ktot, c.dx, c.dy, c.dz, &ctx[g]), "rt_create");
+        check(rt_upload_optics(ctx[g], k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
+        check(rt_set_option(ctx[g], "fixed_dot", c.fixed_dot), "rt_set_option");
+    }
+    auto t1 = std::chrono::high_resolution_clock::now();
+    rt_slab_info slabs;
+    check(rt_get_slabs(ctx[0], &slabs), "rt_get_slabs");
+    std::cout << "Duration cloud-mask computation: " << std::setprecision(5)
+              << std::chrono::duration<double>(t1 - t0).count() << " (s)" << std::endl;
+    std::cout << slabs.cloud_min << " - " << slabs.cloud_max << std::endl;      // raytracer_3d.cu:130
+
+    std::vector<std::vector<uint64_t>> host(RT_N_TALLIES), part(RT_N_TALLIES);
+    for (int t = 0; t < RT_N_TALLIES; ++t)
+    {
+        host[t].resize(t < RT_ATMOS_DIRECT ? ncol : ncell);
+        part[t].resize(host[t].size());
+    }
+
+    for (size_t run_idx = 0; run_idx < c.zenith_deg.size(); ++run_idx)
+    {
+        const float zen = static_cast<float>(c.zenith_deg[run_idx] * (M_PI / 180.));   // raytracer_3d.cu:25
+        const float azi = static_cast<float>(c.azimuth_deg * (M_PI / 180.));
+        for (int g = 0; g < c.ngpus; ++g)
+        {
+            check(rt_set_scene(ctx[g], zen, azi, c.albedo), "rt_set_scene");
+            check(rt_reset_tallies(ctx[g]), "rt_reset_tallies");
+        }
+        auto s0 = std::chrono::high_resolution_clock::now();
+        // photon IDs [0, n) split into contiguous shards, one per GPU; launches are asynchronous
+        const uint64_t base = n_photons / c.ngpus, rem = n_photons % c.ngpus;
+        uint64_t begin = 0;
+        for (int g = 0; g < c.ngpus; ++g)
+        {
+            const uint64_t cnt = base + ((uint64_t)g < rem ? 1 : 0);
+            check(rt_trace(ctx[g], c.seed, begin, cnt), "rt_trace");
+            begin += cnt;
+        }
+        for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
+        auto s1 = std::chrono::high_resolution_clock::now();
+        const double dur = std::chrono::duration<double>(s1 - s0).count();
+        std::cout << "Duration: " << std::setprecision(5) << dur << " (s)" << std::endl;  // raytracer_3d.cu:169
+        std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons / dur << std::endl;
+
+        for (int g = 0; g < c.ngpus; ++g)
+        {
+            uint64_t* ptrs[RT_N_TALLIES];
+            for (int t = 0; t < RT_N_TALLIES; ++t) ptrs[t] = g == 0 ? host[t].data() : part[t].data();
+            check(rt_download_tallies(ctx[g], ptrs), "rt_download_tallies");
+            if (g > 0)
+                for (int t = 0; t < RT_N_TALLIES; ++t)
+                    for (size_t i = 0; i < host[t].size(); ++i) host[t][i] += part[t][i];
+        }
+        std::string dir = c.outdir;
+        if (c.zenith_deg.size() > 1)
+        {
+            std::ostringstream d;
+            d << c.outdir << "/zenith_" << std::setw(2) << std::setfill('0') << (int)std::lround(c.zenith_deg[run_idx]);
+            dir = d.str();
+            mkdir(dir.c_str(), 0777);
+            std::cout << "Writing " << dir << std::endl;
+        }
+        for (int t = 0; t < RT_N_TALLIES; ++t) save_binary(dir, kTallyNames[t], host[t].data(), host[t].size());
+    }
+    for (int g = 0; g < c.ngpus; ++g) rt_destroy(ctx[g]);
+}
+} // namespace drv

@@ -1,0 +1,67 @@
+"""The two drop-in executables (drivers/) on the GPU: CLI contract, stdout lines, file formats,
+and tallies bit-identical to the CPU oracle on the same scene and photon IDs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd import scenes, TALLY_NAMES
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU = os.path.join(ROOT, "drivers", "raytracer_3d_gpu")
+IO = os.path.join(ROOT, "drivers", "raytracer_3d_io_gpu")
+
+
+def _read(d, sc):
+    out = {}
+    for n in TALLY_NAMES:
+        shape = (sc.ktot, sc.jtot, sc.itot) if n.startswith("atmos") else (sc.jtot, sc.itot)
+        out[n] = np.fromfile(os.path.join(d, n + ".bin"), dtype=np.uint64).reshape(shape)
+    return out
+
+
+def test_builtin_scene_driver(tmp_path):
+    r = subprocess.run([GPU, "18"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith("Shooting 262144 photons (8 per thread)")
+    assert lines[1].startswith("Duration cloud-mask computation:") and lines[2] == "1000 - 1500"
+    assert any(l.startswith("Duration: ") and l.endswith("(s)") for l in lines)
+    sc = scenes.block_cloud()
+    got = _read(tmp_path, sc)
+    want, _ = O.photon_oracle(sc, 0, 0, 1 << 18)
+    for n in TALLY_NAMES:
+        assert np.array_equal(got[n], want[n]), n
+    assert O.balance(got) == 0
+
+
+def test_cli_contract(tmp_path):
+    r = subprocess.run([GPU], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "please add the exponent n" in r.stdout
+    r = subprocess.run([GPU, "10"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "must be larger than 32768" in r.stderr
+    r = subprocess.run([IO, "16", "--itot=8", "--jtot=8", "--ktot=8"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and 'Cannot read file "k_ext_gas.bin"' in r.stderr
+
+
+def test_file_input_driver_and_zenith_sweep(tmp_path):
+    sc = scenes.tiny()
+    sc.write(str(tmp_path))
+    dims = [f"--itot={sc.itot}", f"--jtot={sc.jtot}", f"--ktot={sc.ktot}", f"--dx={sc.dx}", f"--dy={sc.dy}", f"--dz={sc.dz}"]
+    r = subprocess.run([IO, "16", "--seed=3", *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want, _ = O.photon_oracle(sc, 3, 0, 1 << 16)
+    got = _read(tmp_path, sc)
+    for n in TALLY_NAMES:
+        assert np.array_equal(got[n], want[n]), n
+    r = subprocess.run([IO, "15", "--zenith=0,30,60", *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for zen in (0, 30, 60):
+        sc.zenith_deg = float(zen)
+        want, _ = O.photon_oracle(sc, 0, 0, 1 << 15)
+        got = _read(tmp_path / f"zenith_{zen:02d}", sc)
+        for n in TALLY_NAMES:
+            assert np.array_equal(got[n], want[n]), (zen, n)
