@@ -60,7 +60,7 @@ def cpu_baseline(scene, seconds):
     import oracle_lib as O
     cores = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
     s64 = O.scene_to_f64(scene)
-    probe = 200_000
+    probe = 1_000_000
     t0 = time.perf_counter()
     t, _ = O.cpu_ref(s64, probe, nthreads=cores)
     dt = time.perf_counter() - t0
