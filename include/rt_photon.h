@@ -52,7 +52,7 @@ enum rt_tally
  * figure of the roofline. */
 enum rt_event
 {
-    RT_EV_STEPS = 0,        /* loop iterations: one free-path sample each */
+    RT_EV_STEPS = 0,        /* traversal steps: one majorant region crossed or collision site reached */
     RT_EV_COLLISION_TESTS,  /* gathers of k_tot */
     RT_EV_REAL,             /* non-null collisions (gather of ssa) */
     RT_EV_SCATTER,          /* scatterings (gather of asy, k_cloud) */
@@ -60,7 +60,7 @@ enum rt_event
     RT_EV_SURFACE,          /* surface arrivals */
     RT_EV_TOA,              /* escapes at the top */
     RT_EV_ABSORB,           /* absorptions in the atmosphere */
-    RT_EV_TRANSITION,       /* majorant-region crossings */
+    RT_EV_TRANSITION,       /* faces of majorant regions crossed (domain top and bottom included) */
     RT_EV_ABORT,            /* photons abandoned by the step/NaN guard; must stay 0 */
     RT_N_EVENTS
 };
@@ -77,6 +77,9 @@ typedef struct rt_slab_info
     float cloud_min;    /* = k_lo*dz,      cloud_dims[0] of the reference (0 if none) */
     float cloud_max;    /* = (k_hi+1)*dz,  cloud_dims[1] of the reference (0 if none) */
     float sun[3];       /* direction cosines of the direct beam */
+    int gslab;          /* index of the slab refined into a grid of local majorants, -1 if none */
+    int nci, ncj, nck;  /* supervoxels of that grid per axis */
+    float hx, hy, hz;   /* supervoxel edge lengths (m) */
 } rt_slab_info;
 
 /* Message of the last failed call on this thread. */
@@ -113,7 +116,12 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
 /* Options by name:
  *   "fixed_dot"      0 (default): dot() as the reference writes it, raytracer_kernels.cu:70-74;
  *                    1: the mathematically intended v1.z*v2.z
- *   "blocks_per_cu"  workgroups of 256 lanes per compute unit of the persistent launch (default 8)
+ *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
+ *                    (default 8, 8, 4; 0 = slab majorants only, the reference's scheme)
+ *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
+ *                    scatter stage before it runs, and the number of traversing lanes below which
+ *                    waiting lanes are served regardless (scheduling only: results do not change)
+ *   "blocks_per_cu"  workgroups of 256 lanes per compute unit of the persistent launch (default 6)
  *   "stats"          1: rt_trace also counts events (rt_get_events); 0 (default): it does not */
 int rt_set_option(rt_context* ctx, const char* name, long long value);
 
@@ -155,6 +163,10 @@ int rt_bind_tally_buffer(rt_context* ctx, void* device_ptr, size_t n_words);
 
 /* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
 int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
+
+/* The majorant grid of the cloud slab as nck*ncj*nci pairs {M, 1/M}, [ck][cj][ci] (n_pairs must
+ * equal nck*ncj*nci of rt_get_slabs). Test/diagnostic access; no counterpart in the reference. */
+int rt_get_majorants(rt_context* ctx, float* out_pairs, size_t n_pairs);
 
 /* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
  * but RT_EV_ABORT). Synchronises first. */

@@ -18,10 +18,12 @@
  * -ffp-contract=off; every fused multiply-add is written out as fmaf().
  *
  * Reference lines restated (relative to /root/reference/src/):
- *   launch at TOA ............ raytracer_kernels.cu:180-208   (rt_launch)
+ *   launch at TOA ............ raytracer_kernels.cu:180-208
  *   free path ................ raytracer_kernels.cu:165-170, 367
- *   slab majorants/transition  raytracer_kernels.cu:360-415   (restated as explicit slab state +
- *                              parametric distance to the next slab face)
+ *   slab majorants/transition  raytracer_kernels.cu:360-415   (restated as explicit region state,
+ *                              parametric distance to the next region face and an optical depth
+ *                              carried across faces; the cloud slab optionally refined into a
+ *                              grid of local majorants)
  *   surface / TOA ............ raytracer_kernels.cu:417-434, 455-499
  *   periodic wrap ............ raytracer_kernels.cu:440-448
  *   cell index ............... raytracer_kernels.cu:173-178
@@ -46,7 +48,6 @@
 #define RT_TWO_PI 6.2831854820251465f   /* Float(2.*M_PI) */
 #define RT_MAX_STEPS (1u << 22)
 
-enum { TAG_LAUNCH = 0, TAG_STEP = 1, TAG_SCATTER = 2 };
 
 /* ---------------------------------------------------------------- Philox4x32-10 ---------- */
 /* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11). */
@@ -69,6 +70,7 @@ void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* one block per event: counter = (photon id low, photon id high, event index, 0), key = seed */
 static inline void draw(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, uint32_t w[4])
 {
     const uint32_t ctr[4] = {(uint32_t)pid, (uint32_t)(pid >> 32), step, tag};
@@ -202,8 +204,13 @@ typedef struct
     float dx, dy, dz;
     float zenith_rad, azimuth_rad, albedo;
     int fixed_dot; /* 0 = dot() as the reference writes it (v1.z*v1.z), 1 = v1.z*v2.z */
+    int sx, sy, sz; /* supervoxel size in cells for the majorant grid of the cloud slab; 0 = none */
 } oracle_scene_t;
 
+/* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
+ * raytracer_kernels.cu:360-362), one majorant each; optionally the cloud slab is refined into a
+ * grid of supervoxels (sx*sy*sz cells) with local majorants (north_star: "voxel-DDA traversal",
+ * SURVEY.md §7 "majorant super-grid"). */
 typedef struct
 {
     int nslab;          /* 1..3 non-empty horizontal slabs, bottom to top */
@@ -212,7 +219,13 @@ typedef struct
     float inv_kmaj[3];
     int k_lo, k_hi;     /* cloud levels (asy > 0), -1 if none */
     float sun[3];       /* direction of the direct beam, raytracer_3d.cu:25-30 */
+    int gslab;          /* index of the gridded slab, -1 if none */
+    int nci, ncj, nck;  /* supervoxels per axis */
+    float hx, hy, hz;   /* supervoxel edge lengths */
+    float* maj;         /* nck*ncj*nci pairs {M, 1/M}; owned, freed by oracle_free_slabs */
 } oracle_slabs_t;
+
+void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; }
 
 /* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
  * raytracer_3d_io.cu:60-77 (majorants), per slab: max over the slab's levels of gas + cloud. */
@@ -237,11 +250,12 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
     }
     out->k_lo = k_lo; out->k_hi = k_hi;
 
-    int lo[3], hi[3], n = 0;
+    int lo[3], hi[3], n = 0, g = -1;
     if (k_lo < 0) { lo[0] = 0; hi[0] = sc->ktot; n = 1; }
     else
     {
         if (k_lo > 0) { lo[n] = 0; hi[n] = k_lo; ++n; }
+        g = n;
         lo[n] = k_lo; hi[n] = k_hi + 1; ++n;
         if (k_hi + 1 < sc->ktot) { lo[n] = k_hi + 1; hi[n] = sc->ktot; ++n; }
     }
@@ -256,14 +270,45 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         out->zface[s] = (float)lo[s] * sc->dz;
     }
     out->zface[n] = (float)sc->ktot * sc->dz;
+    for (int s = n + 1; s < 4; ++s) out->zface[s] = out->zface[n];
     /* raytracer_3d.cu:25-30: angles are floats, cosines in float. Host libm is fine here: the
      * product computes the same three numbers on the host and hands them to the kernel, so they
      * are inputs of the traced path, not results of it. */
     out->sun[0] = -sinf(sc->zenith_rad) * cosf(sc->azimuth_rad);
     out->sun[1] = -sinf(sc->zenith_rad) * sinf(sc->azimuth_rad);
     out->sun[2] = -cosf(sc->zenith_rad);
-    for (int s = n + 1; s < 4; ++s) out->zface[s] = out->zface[n];
     free(lev_max);
+
+    /* majorant grid of the cloud slab */
+    out->gslab = -1; out->nci = out->ncj = out->nck = 0; out->hx = out->hy = out->hz = 0.0f; out->maj = NULL;
+    if (g >= 0 && sc->sx > 0 && sc->sy > 0 && sc->sz > 0)
+    {
+        const int nci = (sc->itot + sc->sx - 1) / sc->sx, ncj = (sc->jtot + sc->sy - 1) / sc->sy;
+        const int nck = (k_hi + 1 - k_lo + sc->sz - 1) / sc->sz;
+        out->gslab = g; out->nci = nci; out->ncj = ncj; out->nck = nck;
+        out->hx = (float)sc->sx * sc->dx; out->hy = (float)sc->sy * sc->dy; out->hz = (float)sc->sz * sc->dz;
+        out->maj = (float*)malloc(sizeof(float) * 2 * (size_t)nci * ncj * nck);
+        for (int ck = 0; ck < nck; ++ck)
+            for (int cj = 0; cj < ncj; ++cj)
+                for (int ci = 0; ci < nci; ++ci)
+                {
+                    float m = 0.0f;
+                    const int k1 = k_lo + (ck + 1) * sc->sz < k_hi + 1 ? k_lo + (ck + 1) * sc->sz : k_hi + 1;
+                    const int j1 = (cj + 1) * sc->sy < sc->jtot ? (cj + 1) * sc->sy : sc->jtot;
+                    const int i1 = (ci + 1) * sc->sx < sc->itot ? (ci + 1) * sc->sx : sc->itot;
+                    for (int k = k_lo + ck * sc->sz; k < k1; ++k)
+                        for (int j = cj * sc->sy; j < j1; ++j)
+                            for (int i = ci * sc->sx; i < i1; ++i)
+                            {
+                                const size_t c = (size_t)i + (size_t)j * sc->itot + (size_t)k * nlev;
+                                const float kt = k_gas[c] + k_cloud[c];
+                                if (kt > m) m = kt;
+                            }
+                    const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
+                    out->maj[2 * e] = m;
+                    out->maj[2 * e + 1] = 1.0f / m;
+                }
+    }
 }
 
 /* ---------------------------------------------------------------- the photon life cycle -- */
@@ -280,6 +325,21 @@ static inline void bump(uint64_t* p)
     ++*p;
 }
 
+/* distance along the ray (in units of the direction vector) to a face; negative (already past
+ * the face by rounding) -> 0, NaN (zero direction component on the face) -> infinity */
+static inline float face_distance(float face, float pos, float inv_u)
+{
+    const float t = (face - pos) * inv_u;
+    return t >= 0.0f ? t : (t < 0.0f ? 0.0f : INFINITY);
+}
+
+/* Draw layout: ONE Philox block per event, counter = (pid_lo, pid_hi, event index, 0):
+ *   launch:     w0 -> x, w1 -> y, w2 -> first optical depth
+ *   collision:  w0 -> classifier r (and gas/cloud choice), w1 -> next optical depth,
+ *               w2 -> scattering cosine, w3 -> scattering azimuth
+ *   surface:    w0 -> albedo test, w1 -> Lambert cosine, w2 -> Lambert azimuth
+ * The sampled optical depth is carried across majorant regions (decremented by M * t on every
+ * face crossing), so crossings consume no random numbers. */
 static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                       const float* k_gas, const float* k_cloud, const float* ssa, const float* asy,
                       uint64_t seed, uint64_t pid, const tallies_t* t, uint64_t* ev)
@@ -288,17 +348,26 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
     const float xs = (float)itot * sc->dx, ys = (float)jtot * sc->dy;
     const float inv_xs = 1.0f / xs, inv_ys = 1.0f / ys;
     const float inv_dx = 1.0f / sc->dx, inv_dy = 1.0f / sc->dy, inv_dz = 1.0f / sc->dz;
+    const int g = sl->gslab, nci = sl->nci, ncj = sl->ncj, nck = sl->nck;
+    const float hx = sl->hx, hy = sl->hy, hz = sl->hz;
+    const float inv_hx = g >= 0 ? 1.0f / hx : 0.0f, inv_hy = g >= 0 ? 1.0f / hy : 0.0f;
+    const float zc0 = g >= 0 ? sl->zface[g] : 0.0f, zc1 = g >= 0 ? sl->zface[g + 1] : 0.0f;
 
     uint32_t w[4];
+    uint32_t nev = 0;
 
     /* launch, raytracer_kernels.cu:180-208 */
-    draw(seed, pid, 0u, TAG_LAUNCH, w);
+    draw(seed, pid, nev++, 0u, w);
     float x = xs * u01(w[0]);
     float y = ys * u01(w[1]);
+    float tau = free_path_tau(u01(w[2]));
+    if (!(tau > 0.0f)) tau = 0.0f;
     float z = sl->zface[sl->nslab];
     float ux = sl->sun[0], uy = sl->sun[1], uz = sl->sun[2];
-    float inv_uz = 1.0f / uz;
+    float iux = 1.0f / ux, iuy = 1.0f / uy, iuz = 1.0f / uz;
     int slab = sl->nslab - 1;
+    int ci = 0, cj = 0, ck = 0;
+    if (slab == g) { ci = cell_of(x, inv_hx, nci); cj = cell_of(y, inv_hy, ncj); ck = nck - 1; }
     int diffuse = 0;
     {
         const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot);
@@ -313,124 +382,178 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             return;
         }
         ++ev[EV_STEP];
-        draw(seed, pid, step, TAG_STEP, w);
 
-        const float inv_k = sl->inv_kmaj[slab];
-        const float tau = free_path_tau(u01(w[0]));
-        float dn = tau * inv_k;                       /* raytracer_kernels.cu:367 */
-        if (!(dn > RT_EPS)) dn = RT_EPS;
-
-        /* distance, in units of the direction vector, to the face this photon is heading for */
-        const int up = uz > 0.0f;
-        const float face = up ? sl->zface[slab + 1] : sl->zface[slab];
-        float t_face = (face - z) * inv_uz;
-        if (!(t_face >= 0.0f)) t_face = INFINITY;
-        const int hit = t_face <= dn;
-        const float tt = hit ? t_face : dn;
-
-        x = wrap_periodic(fmaf(ux, tt, x), xs, inv_xs);
-        y = wrap_periodic(fmaf(uy, tt, y), ys, inv_ys);
-        z = hit ? face : fmaf(uz, tt, z);
-
-        const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot);
-        const size_t ij = (size_t)i + (size_t)j * itot;
-
-        if (hit && !up && slab == 0)
+        /* ---- traverse one majorant region ---- */
+        const int gridded = slab == g;
+        float M, invM, tx, ty, tz, fz;
+        const float xlo = (float)ci * hx, xhi = (ci + 1 == nci) ? xs : (float)(ci + 1) * hx;
+        const float ylo = (float)cj * hy, yhi = (cj + 1 == ncj) ? ys : (float)(cj + 1) * hy;
+        const float fx = ux > 0.0f ? xhi : xlo, fy = uy > 0.0f ? yhi : ylo;
+        if (gridded)
         {
-            /* surface, raytracer_kernels.cu:455-486 */
-            ++ev[EV_SFC];
-            bump(diffuse ? &t->sfc_dif[ij] : &t->sfc_dir[ij]);
-            if (u01(w[1]) <= sc->albedo)
-            {
-                bump(&t->sfc_up[ij]);
-                const float mu = sqrtf(u01(w[2]));
-                float sa, ca;
-                oracle_sincos2pi(u01(w[3]), &sa, &ca);
-                ux = mu * sa;
-                uy = mu * ca;
-                uz = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
-                inv_uz = 1.0f / uz;
-                diffuse = 1;
-            }
-            else
-                return;
-        }
-        else if (hit && up && slab == sl->nslab - 1)
-        {
-            /* top of atmosphere, raytracer_kernels.cu:487-499 */
-            ++ev[EV_TOA];
-            bump(&t->toa_up[ij]);
-            return;
-        }
-        else if (hit)
-        {
-            /* slab transition, raytracer_kernels.cu:376-415: resample the free path with the
-             * next slab's majorant (memoryless), nothing else happens */
-            ++ev[EV_TRANS];
-            slab += up ? 1 : -1;
+            const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
+            M = sl->maj[2 * e]; invM = sl->maj[2 * e + 1];
+            const float zlo = fmaf((float)ck, hz, zc0), zhi = (ck + 1 == nck) ? zc1 : fmaf((float)(ck + 1), hz, zc0);
+            fz = uz > 0.0f ? zhi : zlo;
+            tx = face_distance(fx, x, iux); ty = face_distance(fy, y, iuy); tz = face_distance(fz, z, iuz);
         }
         else
         {
-            /* collision test, raytracer_kernels.cu:507-566 */
-            ++ev[EV_COLL];
-            const int k = cell_of(z, inv_dz, ktot);
-            const size_t c = ij + (size_t)k * itot * jtot;
-            const float kt = k_gas[c] + k_cloud[c];
-            const float r = u01(w[1]);
-            const float p_real = kt * inv_k;
-            if (r >= p_real)
+            M = sl->kmaj[slab]; invM = sl->inv_kmaj[slab];
+            fz = uz > 0.0f ? sl->zface[slab + 1] : sl->zface[slab];
+            tx = INFINITY; ty = INFINITY; tz = face_distance(fz, z, iuz);
+        }
+        float t_exit = tx; int axis = 0;
+        if (ty < t_exit) { t_exit = ty; axis = 1; }
+        if (tz < t_exit) { t_exit = tz; axis = 2; }
+        const float dn = M > 0.0f ? tau * invM : INFINITY;       /* raytracer_kernels.cu:367 */
+        const int hit = t_exit <= dn;
+        const float tt = hit ? t_exit : dn;
+        x = fmaf(ux, tt, x); y = fmaf(uy, tt, y); z = fmaf(uz, tt, z);
+        if (!gridded) { x = wrap_periodic(x, xs, inv_xs); y = wrap_periodic(y, ys, inv_ys); }
+
+        if (hit)
+        {
+            ++ev[EV_TRANS];
+            tau = fmaf(-tt, M, tau);
+            if (!(tau > 0.0f)) tau = 0.0f;
+            int leave = 0;                       /* +1: leaves the slab upwards, -1: downwards */
+            if (axis == 0)
             {
-                /* null collision */
+                x = fx; ci += ux > 0.0f ? 1 : -1;
+                if (ci == nci) { ci = 0; x = 0.0f; }
+                if (ci < 0) { ci = nci - 1; x = xs; }
             }
-            else if (r <= ssa[c] * p_real)
+            else if (axis == 1)
             {
-                ++ev[EV_REAL]; ++ev[EV_SCAT];
-                uint32_t v[4];
-                draw(seed, pid, step, TAG_SCATTER, v);
-                const int from_cloud = u01(v[0]) < k_cloud[c] / kt;
-                if (from_cloud) ++ev[EV_CSCAT];
-                const float mu = from_cloud ? henyey_mu(asy[c], u01(v[1])) : rayleigh_mu(u01(v[1]));
-                /* raytracer_kernels.cu:523. In float the inverse CDFs can return |mu| a few ulp
-                 * above 1, which makes the radicand negative (NaN direction in the reference);
-                 * clamped at 0 here (SURVEY.md §7 "float edge cases"). */
-                const float sn = sqrtf(fmaxf(fmaf(-mu, mu, 1.0f) + RT_EPS, 0.0f));
-
-                /* frame, raytracer_kernels.cu:525-541 */
-                float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                if (fabsf(ux) < fabsf(uy))
-                {
-                    if (fabsf(ux) < fabsf(uz)) ax = 1.0f; else az = 1.0f;
-                }
-                else
-                {
-                    if (fabsf(uy) < fabsf(uz)) ay = 1.0f; else az = 1.0f;
-                }
-                /* dot(t1, dir): the reference's third term is t1.z*t1.z (:73) */
-                const float proj = sc->fixed_dot ? fmaf(az, uz, fmaf(ay, uy, ax * ux))
-                                                 : fmaf(az, az, fmaf(ay, uy, ax * ux));
-                float ox = fmaf(-proj, ux, ax), oy = fmaf(-proj, uy, ay), oz = fmaf(-proj, uz, az);
-                const float inv_len = 1.0f / sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
-                ox *= inv_len; oy *= inv_len; oz *= inv_len;
-                const float bx = fmaf(uy, oz, -(uz * oy));
-                const float by = fmaf(uz, ox, -(ux * oz));
-                const float bz = fmaf(ux, oy, -(uy * ox));
-
-                float sp, cp;
-                oracle_sincos2pi(u01(v[2]), &sp, &cp);
-                /* raytracer_kernels.cu:545-546 */
-                const float nx = fmaf(mu, ux, sn * fmaf(sp, ox, cp * bx));
-                const float ny = fmaf(mu, uy, sn * fmaf(sp, oy, cp * by));
-                const float nz = fmaf(mu, uz, sn * fmaf(sp, oz, cp * bz));
-                ux = nx; uy = ny; uz = nz;
-                inv_uz = 1.0f / uz;
-                diffuse = 1;
+                y = fy; cj += uy > 0.0f ? 1 : -1;
+                if (cj == ncj) { cj = 0; y = 0.0f; }
+                if (cj < 0) { cj = ncj - 1; y = ys; }
             }
             else
             {
-                ++ev[EV_REAL]; ++ev[EV_ABS];
-                bump(diffuse ? &t->atm_dif[c] : &t->atm_dir[c]);
-                return;
+                z = fz;
+                const int up = uz > 0.0f;
+                if (gridded)
+                {
+                    const int nk = ck + (up ? 1 : -1);
+                    if (nk >= 0 && nk < nck) ck = nk; else leave = up ? 1 : -1;
+                }
+                else
+                    leave = up ? 1 : -1;
             }
+            if (leave != 0)
+            {
+                const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot);
+                const size_t ij = (size_t)i + (size_t)j * itot;
+                if (leave > 0 && slab == sl->nslab - 1)
+                {
+                    /* top of atmosphere, raytracer_kernels.cu:487-499 */
+                    ++ev[EV_TOA];
+                    bump(&t->toa_up[ij]);
+                    return;
+                }
+                else if (leave < 0 && slab == 0)
+                {
+                    /* surface, raytracer_kernels.cu:455-486 */
+                    ++ev[EV_SFC];
+                    bump(diffuse ? &t->sfc_dif[ij] : &t->sfc_dir[ij]);
+                    draw(seed, pid, nev++, 0u, w);
+                    if (u01(w[0]) <= sc->albedo)
+                    {
+                        bump(&t->sfc_up[ij]);
+                        const float mu = sqrtf(u01(w[1]));
+                        float sa, ca;
+                        oracle_sincos2pi(u01(w[2]), &sa, &ca);
+                        ux = mu * sa;
+                        uy = mu * ca;
+                        uz = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
+                        iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                        diffuse = 1;
+                    }
+                    else
+                        return;
+                }
+                else
+                {
+                    /* next slab, raytracer_kernels.cu:376-415 */
+                    slab += leave;
+                    if (slab == g)
+                    {
+                        ci = cell_of(x, inv_hx, nci); cj = cell_of(y, inv_hy, ncj);
+                        ck = leave > 0 ? 0 : nck - 1;
+                    }
+                }
+            }
+            continue;
+        }
+
+        /* ---- collision test, raytracer_kernels.cu:507-566 ---- */
+        ++ev[EV_COLL];
+        const int i = cell_of(x, inv_dx, itot), j = cell_of(y, inv_dy, jtot), k = cell_of(z, inv_dz, ktot);
+        const size_t c = (size_t)i + (size_t)j * itot + (size_t)k * itot * jtot;
+        const float kt = k_gas[c] + k_cloud[c];
+        draw(seed, pid, nev++, 0u, w);
+        const float r = u01(w[0]);
+        const float p_real = kt * invM;
+        if (r >= p_real)
+        {
+            /* null collision: new optical depth, same direction */
+            tau = free_path_tau(u01(w[1]));
+            if (!(tau > 0.0f)) tau = 0.0f;
+            continue;
+        }
+        const float s_scat = ssa[c] * p_real;
+        if (r <= s_scat)
+        {
+            ++ev[EV_REAL]; ++ev[EV_SCAT];
+            tau = free_path_tau(u01(w[1]));
+            if (!(tau > 0.0f)) tau = 0.0f;
+            /* gas or cloud: r is uniform on [0, s_scat] here, so r/s_scat < k_cloud/k_tot decides
+             * (raytracer_kernels.cu:520 draws a fresh number for it) */
+            const int from_cloud = r * kt < s_scat * k_cloud[c];
+            if (from_cloud) ++ev[EV_CSCAT];
+            const float mu = from_cloud ? henyey_mu(asy[c], u01(w[2])) : rayleigh_mu(u01(w[2]));
+            /* raytracer_kernels.cu:523. In float the inverse CDFs can return |mu| a few ulp
+             * above 1, which makes the radicand negative (NaN direction in the reference);
+             * clamped at 0 here (SURVEY.md §7 "float edge cases"). */
+            const float sn = sqrtf(fmaxf(fmaf(-mu, mu, 1.0f) + RT_EPS, 0.0f));
+
+            /* frame, raytracer_kernels.cu:525-541 */
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            if (fabsf(ux) < fabsf(uy))
+            {
+                if (fabsf(ux) < fabsf(uz)) ax = 1.0f; else az = 1.0f;
+            }
+            else
+            {
+                if (fabsf(uy) < fabsf(uz)) ay = 1.0f; else az = 1.0f;
+            }
+            /* dot(t1, dir): the reference's third term is t1.z*t1.z (:73) */
+            const float proj = sc->fixed_dot ? fmaf(az, uz, fmaf(ay, uy, ax * ux))
+                                             : fmaf(az, az, fmaf(ay, uy, ax * ux));
+            float ox = fmaf(-proj, ux, ax), oy = fmaf(-proj, uy, ay), oz = fmaf(-proj, uz, az);
+            const float inv_len = 1.0f / sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+            ox *= inv_len; oy *= inv_len; oz *= inv_len;
+            const float bx = fmaf(uy, oz, -(uz * oy));
+            const float by = fmaf(uz, ox, -(ux * oz));
+            const float bz = fmaf(ux, oy, -(uy * ox));
+
+            float sp, cp;
+            oracle_sincos2pi(u01(w[3]), &sp, &cp);
+            /* raytracer_kernels.cu:545-546 */
+            const float nx = fmaf(mu, ux, sn * fmaf(sp, ox, cp * bx));
+            const float ny = fmaf(mu, uy, sn * fmaf(sp, oy, cp * by));
+            const float nz = fmaf(mu, uz, sn * fmaf(sp, oz, cp * bz));
+            ux = nx; uy = ny; uz = nz;
+            iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+            diffuse = 1;
+        }
+        else
+        {
+            ++ev[EV_REAL]; ++ev[EV_ABS];
+            bump(diffuse ? &t->atm_dif[c] : &t->atm_dir[c]);
+            return;
         }
     }
 }
@@ -469,5 +592,6 @@ int photon_oracle_trace(const oracle_scene_t* sc,
         for (int e = 0; e < EV_N; ++e) ev_total[e] += ev[e];
     }
     if (events) memcpy(events, ev_total, sizeof(ev_total));
+    oracle_free_slabs(&sl);
     return 0;
 }

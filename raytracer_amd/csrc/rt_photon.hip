@@ -58,6 +58,7 @@ struct TraceArgs
     const float* k_tot;       // gas + cloud extinction per cell [k][j][i]
     const float* ssa;         // single-scattering albedo per cell
     const float2* scat;       // {asy, k_cloud} per cell
+    const float2* maj;        // {M, 1/M}: ncoarse supervoxels [ck][cj][ci], then one entry per slab
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
     uint64_t seed;
@@ -68,10 +69,14 @@ struct TraceArgs
     uint32_t ncell;
     float xs, ys, inv_xs, inv_ys, inv_dx, inv_dy, inv_dz;
     float albedo;
-    float sun_x, sun_y, sun_z, inv_sun_z;
+    float sun_x, sun_y, sun_z, inv_sun_x, inv_sun_y, inv_sun_z;
     int nslab;
     float zface[4];
-    float inv_kmaj[3];
+    int gslab;                // index of the slab refined into supervoxels, -1 if none
+    int nci, ncj, nck;
+    uint32_t ncoarse;
+    float hx, hy, hz, inv_hx, inv_hy, zc0, zc1;
+    int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
 };
 
 __device__ __forceinline__ void tally_add(unsigned long long* p)
@@ -80,8 +85,27 @@ __device__ __forceinline__ void tally_add(unsigned long long* p)
     __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// distance along the ray to a face; negative (past the face by rounding) -> 0, NaN -> infinity
+__device__ __forceinline__ float face_distance(float face, float pos, float inv_u)
+{
+    const float t = (face - pos) * inv_u;
+    return t >= 0.0f ? t : (t < 0.0f ? 0.0f : __builtin_inff());
+}
+
+enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5 };
+
 // ------------------------------------------------------------------------------------------
-// The photon life cycle. One lane = one photon at a time; the loop body is one free-path sample.
+// The photon life cycle. One lane = one photon at a time, all photon state in VGPRs.
+//
+// Every lane is a small state machine; the wave runs ONE of three stages per round, chosen from
+// ballots so that the branch is scalar and a stage only costs issue slots when enough lanes need it:
+//   T  traverse  — cheap, most frequent: cross one majorant region or reach a collision site
+//   E  event     — one Philox block per lane: launch (regeneration), collision classification,
+//                  surface reflection
+//   S  scatter   — phase-function sampling and rotation of the direction
+// Lanes waiting for E or S sit masked out until th_event / th_scatter lanes wait (or too few lanes
+// are traversing). Because every random number is keyed on (photon id, event index), the order in
+// which lanes are served does not change any photon's trajectory.
 template <bool FIXED_DOT, bool STATS>
 __global__ void __launch_bounds__(kBlock)
 rt_trace_kernel(const TraceArgs a)
@@ -94,128 +118,45 @@ rt_trace_kernel(const TraceArgs a)
     const float ztop = a.zface[a.nslab];
 
     // photon state
-    float x = 0.f, y = 0.f, z = 0.f, ux = 0.f, uy = 0.f, uz = -1.f, inv_uz = -1.f;
-    uint32_t pid_lo = 0, pid_hi = 0, step = 0;
-    int slab = 0;
+    float x = 0.f, y = 0.f, z = 0.f, ux = 0.f, uy = 0.f, uz = -1.f, iux = 0.f, iuy = 0.f, iuz = -1.f;
+    float tau = 0.f, inv_m = 0.f;
+    uint32_t pid_lo = 0, pid_hi = 0, nev = 0, nstep = 0;
+    int slab = 0, ci = 0, cj = 0, ck = 0;
     bool diffuse = false;
-    bool alive = false;
+    int state = ST_LAUNCH;
+    // collision data handed from stage E to stage S
+    uint32_t cell = 0;
+    float sc_lhs = 0.f, sc_s = 0.f, sc_umu = 0.f, sc_uphi = 0.f;
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
 
     for (;;)
     {
-        if (!alive)
+        if (state == ST_LAUNCH && next_pid >= a.pid_end)
+            state = ST_DONE;
+        const int nT = __popcll(__ballot(state == ST_TRAVERSE));
+        const int nE = __popcll(__ballot(state == ST_LAUNCH || state == ST_COLLIDE || state == ST_SURFACE));
+        const int nS = __popcll(__ballot(state == ST_SCATTER));
+        if (nT + nE + nS == 0)
+            break;
+        const bool starving = nT < a.low_traverse;
+        const bool runS = nS >= a.th_scatter || (starving && nS > 0 && nS >= nE);
+        const bool runE = !runS && (nE >= a.th_event || (starving && nE > 0));
+
+        if (runS)
         {
-            if (next_pid >= a.pid_end)
-                break;
-            // launch at the top of the domain, raytracer_kernels.cu:180-208
-            pid_lo = (uint32_t)next_pid;
-            pid_hi = (uint32_t)(next_pid >> 32);
-            next_pid += stride;
-            const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, TAG_LAUNCH, key0, key1);
-            x = a.xs * u01(w.x);
-            y = a.ys * u01(w.y);
-            z = ztop;
-            ux = a.sun_x; uy = a.sun_y; uz = a.sun_z; inv_uz = a.inv_sun_z;
-            slab = a.nslab - 1;
-            diffuse = false;
-            step = 0;
-            alive = true;
-            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-            tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
-        }
-
-        if (step >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
-        {
-            tally_add(&a.events[RT_EV_ABORT]);
-            alive = false;
-            continue;
-        }
-        if (STATS) ++ev_step;
-
-        const u32x4 w = philox4x32_10(pid_lo, pid_hi, step, TAG_STEP, key0, key1);
-
-        const float inv_k = slab == 0 ? a.inv_kmaj[0] : (slab == 1 ? a.inv_kmaj[1] : a.inv_kmaj[2]);
-        const float tau = free_path_tau(u01(w.x));
-        float dn = tau * inv_k;                         // raytracer_kernels.cu:367
-        dn = (dn > RT_EPS) ? dn : RT_EPS;
-
-        // parametric distance to the slab face this photon is heading for
-        const bool up = uz > 0.0f;
-        const int fi = up ? slab + 1 : slab;
-        const float face = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3]));
-        float t_face = (face - z) * inv_uz;
-        t_face = (t_face >= 0.0f) ? t_face : __builtin_inff();
-        const bool hit = t_face <= dn;
-        const float tt = hit ? t_face : dn;
-
-        x = wrap_periodic(fma_(ux, tt, x), a.xs, a.inv_xs);
-        y = wrap_periodic(fma_(uy, tt, y), a.ys, a.inv_ys);
-        z = hit ? face : fma_(uz, tt, z);
-
-        const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-        const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
-
-        if (hit && !up && slab == 0)
-        {
-            // surface, raytracer_kernels.cu:455-486
-            if (STATS) ++ev_sfc;
-            tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]);
-            if (u01(w.y) <= a.albedo)
+            if (state == ST_SCATTER)
             {
-                tally_add(&a.tallies[4u * a.ncol + ij]);
-                const float mu = __builtin_sqrtf(u01(w.z));
-                float sa, ca;
-                rt_sincos2pi(u01(w.w), sa, ca);
-                ux = mu * sa;
-                uy = mu * ca;
-                uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
-                inv_uz = 1.0f / uz;
-                diffuse = true;
-            }
-            else
-                alive = false;
-        }
-        else if (hit && up && slab == a.nslab - 1)
-        {
-            // top of the atmosphere, raytracer_kernels.cu:487-499
-            if (STATS) ++ev_toa;
-            tally_add(&a.tallies[a.ncol + ij]);
-            alive = false;
-        }
-        else if (hit)
-        {
-            // slab transition, raytracer_kernels.cu:376-415
-            if (STATS) ++ev_trans;
-            slab += up ? 1 : -1;
-        }
-        else
-        {
-            // collision test, raytracer_kernels.cu:507-566
-            if (STATS) ++ev_coll;
-            const int k = cell_of(z, a.inv_dz, a.ktot);
-            const uint32_t c = ij + (uint32_t)k * a.ncol;
-            const float kt = a.k_tot[c];
-            const float r = u01(w.y);
-            const float p_real = kt * inv_k;
-            if (r >= p_real)
-            {
-                // null collision
-            }
-            else if (r <= a.ssa[c] * p_real)
-            {
-                if (STATS) { ++ev_real; ++ev_scat; }
-                const u32x4 v = philox4x32_10(pid_lo, pid_hi, step, TAG_SCATTER, key0, key1);
-                const float2 ak = a.scat[c];                    // {asy, k_cloud}
-                const bool from_cloud = u01(v.x) < ak.y / kt;
-                if (STATS && from_cloud) ++ev_cscat;
-                const float mu = from_cloud ? henyey_mu(ak.x, u01(v.y)) : rayleigh_mu(u01(v.y));
+                // phase function + rotation, raytracer_kernels.cu:520-548
+                const float2 ak = a.scat[cell];                 // {asy, k_cloud}
+                const bool from_cloud = sc_lhs < sc_s * ak.y;   // r/s < k_cloud/k_tot
+                if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                const float mu = from_cloud ? henyey_mu(ak.x, sc_umu) : rayleigh_mu(sc_umu);
                 // |mu| can come out a few ulp above 1 in float: clamp the radicand (the reference
                 // would produce a NaN direction here, raytracer_kernels.cu:523)
                 const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
 
-                // frame, raytracer_kernels.cu:525-541
                 float ax = 0.0f, ay = 0.0f, az = 0.0f;
                 const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
                 if (fx < fy)
@@ -237,22 +178,221 @@ rt_trace_kernel(const TraceArgs a)
                 const float bz = fma_(ux, oy, -(uy * ox));
 
                 float sp, cp;
-                rt_sincos2pi(u01(v.z), sp, cp);
+                rt_sincos2pi(sc_uphi, sp, cp);
                 const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
                 const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
                 const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
                 ux = nx; uy = ny; uz = nz;
-                inv_uz = 1.0f / uz;
+                iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
                 diffuse = true;
-            }
-            else
-            {
-                if (STATS) { ++ev_real; ++ev_abs; }
-                tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncell : 0u) + c]);
-                alive = false;
+                state = ST_TRAVERSE;
             }
         }
-        ++step;
+        else if (runE)
+        {
+            if (state == ST_LAUNCH || state == ST_COLLIDE || state == ST_SURFACE)
+            {
+                float kt = 0.0f;
+                if (state == ST_LAUNCH)
+                {
+                    pid_lo = (uint32_t)next_pid;
+                    pid_hi = (uint32_t)(next_pid >> 32);
+                    next_pid += stride;
+                    nev = 0;
+                    nstep = 0;
+                }
+                else if (state == ST_COLLIDE)
+                {
+                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                    const int k = cell_of(z, a.inv_dz, a.ktot);
+                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
+                    kt = a.k_tot[cell];
+                }
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
+                ++nev;
+
+                if (state == ST_LAUNCH)
+                {
+                    // launch at the top of the domain, raytracer_kernels.cu:180-208
+                    x = a.xs * u01(w.x);
+                    y = a.ys * u01(w.y);
+                    tau = free_path_tau(u01(w.z));
+                    tau = tau > 0.0f ? tau : 0.0f;
+                    z = ztop;
+                    ux = a.sun_x; uy = a.sun_y; uz = a.sun_z;
+                    iux = a.inv_sun_x; iuy = a.inv_sun_y; iuz = a.inv_sun_z;
+                    slab = a.nslab - 1;
+                    ci = 0; cj = 0; ck = 0;
+                    if (slab == a.gslab)
+                    {
+                        ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
+                    }
+                    diffuse = false;
+                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                    tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                    state = ST_TRAVERSE;
+                }
+                else if (state == ST_COLLIDE)
+                {
+                    // collision classification, raytracer_kernels.cu:507-518
+                    if (STATS) ++ev_coll;
+                    const float r = u01(w.x);
+                    const float p_real = kt * inv_m;
+                    state = ST_TRAVERSE;
+                    if (r < p_real)
+                    {
+                        if (STATS) ++ev_real;
+                        const float s_scat = a.ssa[cell] * p_real;
+                        if (r <= s_scat)
+                        {
+                            sc_lhs = r * kt; sc_s = s_scat; sc_umu = u01(w.z); sc_uphi = u01(w.w);
+                            state = ST_SCATTER;
+                        }
+                        else
+                        {
+                            // absorption, raytracer_kernels.cu:551-566
+                            if (STATS) ++ev_abs;
+                            tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncell : 0u) + cell]);
+                            state = ST_LAUNCH;
+                        }
+                    }
+                    // null collision or scattering: the photon goes on with a fresh optical depth
+                    tau = free_path_tau(u01(w.y));
+                    tau = tau > 0.0f ? tau : 0.0f;
+                }
+                else
+                {
+                    // surface: absorb or reflect (Lambertian), raytracer_kernels.cu:463-486
+                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                    const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                    if (u01(w.x) <= a.albedo)
+                    {
+                        tally_add(&a.tallies[4u * a.ncol + ij]);
+                        const float mu = __builtin_sqrtf(u01(w.y));
+                        float sa, ca;
+                        rt_sincos2pi(u01(w.z), sa, ca);
+                        ux = mu * sa;
+                        uy = mu * ca;
+                        uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+                        iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                        diffuse = true;
+                        state = ST_TRAVERSE;
+                    }
+                    else
+                        state = ST_LAUNCH;
+                }
+            }
+        }
+        else
+        {
+            if (state == ST_TRAVERSE)
+            {
+                if (nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
+                {
+                    tally_add(&a.events[RT_EV_ABORT]);
+                    state = ST_LAUNCH;
+                }
+                else
+                {
+                    ++nstep;
+                    if (STATS) ++ev_step;
+                    // ---- cross one majorant region or stop at the collision site ----
+                    const bool gridded = slab == a.gslab;
+                    const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
+                    const float2 mm = a.maj[e];
+                    const float xlo = (float)ci * a.hx, xhi = (ci + 1 == a.nci) ? a.xs : (float)(ci + 1) * a.hx;
+                    const float ylo = (float)cj * a.hy, yhi = (cj + 1 == a.ncj) ? a.ys : (float)(cj + 1) * a.hy;
+                    const float fx = ux > 0.0f ? xhi : xlo, fy = uy > 0.0f ? yhi : ylo;
+                    const bool up = uz > 0.0f;
+                    float fz;
+                    if (gridded)
+                    {
+                        const float zlo = fma_((float)ck, a.hz, a.zc0);
+                        const float zhi = (ck + 1 == a.nck) ? a.zc1 : fma_((float)(ck + 1), a.hz, a.zc0);
+                        fz = up ? zhi : zlo;
+                    }
+                    else
+                    {
+                        const int fi = up ? slab + 1 : slab;
+                        fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3]));
+                    }
+                    const float tx = gridded ? face_distance(fx, x, iux) : __builtin_inff();
+                    const float ty = gridded ? face_distance(fy, y, iuy) : __builtin_inff();
+                    const float tz = face_distance(fz, z, iuz);
+                    float t_exit = tx; int axis = 0;
+                    if (ty < t_exit) { t_exit = ty; axis = 1; }
+                    if (tz < t_exit) { t_exit = tz; axis = 2; }
+                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff();   // raytracer_kernels.cu:367
+                    const bool hit = t_exit <= dn;
+                    const float tt = hit ? t_exit : dn;
+                    x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
+                    if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
+                    inv_m = mm.y;
+
+                    if (!hit)
+                        state = ST_COLLIDE;
+                    else
+                    {
+                        if (STATS) ++ev_trans;
+                        tau = fma_(-tt, mm.x, tau);
+                        tau = tau > 0.0f ? tau : 0.0f;
+                        int leave = 0;
+                        if (axis == 0)
+                        {
+                            x = fx; ci += ux > 0.0f ? 1 : -1;
+                            if (ci == a.nci) { ci = 0; x = 0.0f; }
+                            if (ci < 0) { ci = a.nci - 1; x = a.xs; }
+                        }
+                        else if (axis == 1)
+                        {
+                            y = fy; cj += uy > 0.0f ? 1 : -1;
+                            if (cj == a.ncj) { cj = 0; y = 0.0f; }
+                            if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
+                        }
+                        else
+                        {
+                            z = fz;
+                            if (gridded)
+                            {
+                                const int nk = ck + (up ? 1 : -1);
+                                if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1;
+                            }
+                            else
+                                leave = up ? 1 : -1;
+                        }
+                        if (leave != 0)
+                        {
+                            if (leave > 0 && slab == a.nslab - 1)
+                            {
+                                // top of the atmosphere, raytracer_kernels.cu:487-499
+                                if (STATS) ++ev_toa;
+                                const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                                tally_add(&a.tallies[a.ncol + (uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                                state = ST_LAUNCH;
+                            }
+                            else if (leave < 0 && slab == 0)
+                            {
+                                // surface arrival, raytracer_kernels.cu:455-460; the albedo draw is stage E
+                                if (STATS) ++ev_sfc;
+                                const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + (uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                                state = ST_SURFACE;
+                            }
+                            else
+                            {
+                                // next slab, raytracer_kernels.cu:376-415
+                                slab += leave;
+                                if (slab == a.gslab)
+                                {
+                                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj);
+                                    ck = leave > 0 ? 0 : a.nck - 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
     }
 
     if (STATS)
@@ -265,6 +405,36 @@ rt_trace_kernel(const TraceArgs a)
                 __hip_atomic_fetch_add(&a.events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Majorant grid of the cloud slab: one wave per supervoxel, max of k_tot over its cells, stored
+// as {M, 1/M}. (Generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels.)
+__global__ void __launch_bounds__(64)
+rt_majorant_kernel(const float* __restrict__ k_tot, float2* __restrict__ maj,
+                   int itot, int jtot, uint32_t ncol, int k_lo, int k_end,
+                   int sx, int sy, int sz, int nci, int ncj)
+{
+    const uint32_t e = blockIdx.x;
+    const int ci = e % nci, cj = (e / nci) % ncj, ck = e / (nci * ncj);
+    const int i0 = ci * sx, j0 = cj * sy, k0 = k_lo + ck * sz;
+    const int ni = min(sx, itot - i0), nj = min(sy, jtot - j0), nk = min(sz, k_end - k0);
+    const int n = ni * nj * nk;
+    float m = 0.0f;
+    for (int t = threadIdx.x; t < n; t += 64)
+    {
+        const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
+        const float v = k_tot[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol];
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        const float o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if (threadIdx.x == 0)
+        maj[e] = make_float2(m, 1.0f / m);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -356,6 +526,11 @@ struct rt_context
     float* d_k_tot = nullptr;
     float* d_ssa = nullptr;
     float2* d_scat = nullptr;
+    float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
+    size_t maj_capacity = 0, ncoarse = 0;
+    bool maj_dirty = true;
+    int sgx = 8, sgy = 8, sgz = 4;    // supervoxel size in cells (0 = no grid, slabs only)
+    int th_event = 20, th_scatter = 16, low_traverse = 20;
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
@@ -368,7 +543,7 @@ struct rt_context
     float albedo = 0.2f, zenith = 0, azimuth = 0;
 
     bool fixed_dot = false, stats = false;
-    int blocks_per_cu = 8;
+    int blocks_per_cu = 6;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
@@ -409,6 +584,47 @@ void build_slabs(rt_context* c)
     for (int i = n + 1; i < 4; ++i) s.zface[i] = s.zface[n];
 }
 
+// (Re)builds the majorant table on the device: supervoxels of the cloud slab (if the grid is
+// enabled and a cloud slab exists), followed by one {M, 1/M} entry per slab.
+int build_majorants(rt_context* c)
+{
+    rt_slab_info& s = c->slabs;
+    const int g = (s.k_lo >= 0 && c->sgx > 0 && c->sgy > 0 && c->sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
+    s.gslab = g; s.nci = s.ncj = s.nck = 0; s.hx = s.hy = s.hz = 0.0f;
+    size_t ncoarse = 0;
+    if (g >= 0)
+    {
+        s.nci = (c->itot + c->sgx - 1) / c->sgx;
+        s.ncj = (c->jtot + c->sgy - 1) / c->sgy;
+        s.nck = (s.k_hi + 1 - s.k_lo + c->sgz - 1) / c->sgz;
+        s.hx = (float)c->sgx * c->dx; s.hy = (float)c->sgy * c->dy; s.hz = (float)c->sgz * c->dz;
+        ncoarse = (size_t)s.nci * s.ncj * s.nck;
+        if (s.nci > 32767 || s.ncj > 32767 || ncoarse >= (1ull << 31))
+            return fail(RT_ERR_ARG, "majorant grid %dx%dx%d too large", s.nci, s.ncj, s.nck);
+    }
+    if (ncoarse + 3 > c->maj_capacity)
+    {
+        if (c->d_maj) RT_HIP(hipFree(c->d_maj));
+        c->d_maj = nullptr;
+        RT_HIP(hipMalloc(&c->d_maj, sizeof(float2) * (ncoarse + 3)));
+        c->maj_capacity = ncoarse + 3;
+    }
+    if (ncoarse)
+    {
+        hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)ncoarse), dim3(64), 0, c->stream,
+                           c->d_k_tot, c->d_maj, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
+                           c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
+        RT_HIP(hipGetLastError());
+    }
+    float2 slab_m[3];
+    for (int i = 0; i < 3; ++i) slab_m[i] = make_float2(s.kmaj[i], c->inv_kmaj[i]);
+    RT_HIP(hipMemcpyAsync(c->d_maj + ncoarse, slab_m, sizeof(slab_m), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    c->ncoarse = ncoarse;
+    c->maj_dirty = false;
+    return RT_OK;
+}
+
 int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, const float* d_ssa, const float* d_asy)
 {
     unsigned int* d_lev = nullptr;
@@ -435,6 +651,7 @@ int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, co
     }
     build_slabs(c);
     c->have_optics = true;
+    c->maj_dirty = true;
     return RT_OK;
 }
 } // namespace
@@ -503,6 +720,7 @@ int rt_destroy(rt_context* c)
     if (c->d_k_tot) (void)hipFree(c->d_k_tot);
     if (c->d_ssa) (void)hipFree(c->d_ssa);
     if (c->d_scat) (void)hipFree(c->d_scat);
+    if (c->d_maj) (void)hipFree(c->d_maj);
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -562,6 +780,17 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value < 1 || value > 16) return fail(RT_ERR_ARG, "rt_set_option: blocks_per_cu %lld outside [1,16]", value);
         c->blocks_per_cu = (int)value;
     }
+    else if (!strcmp(name, "supergrid_x") || !strcmp(name, "supergrid_y") || !strcmp(name, "supergrid_z"))
+    {
+        if (value < 0 || value > 4096) return fail(RT_ERR_ARG, "rt_set_option: %s %lld outside [0,4096]", name, value);
+        (name[10] == 'x' ? c->sgx : (name[10] == 'y' ? c->sgy : c->sgz)) = (int)value;
+        c->maj_dirty = true;
+    }
+    else if (!strcmp(name, "th_event") || !strcmp(name, "th_scatter") || !strcmp(name, "low_traverse"))
+    {
+        if (value < 1 || value > 64) return fail(RT_ERR_ARG, "rt_set_option: %s %lld outside [1,64]", name, value);
+        (!strcmp(name, "th_event") ? c->th_event : (!strcmp(name, "th_scatter") ? c->th_scatter : c->low_traverse)) = (int)value;
+    }
     else return fail(RT_ERR_ARG, "rt_set_option: unknown option \"%s\"", name);
     return RT_OK;
 }
@@ -581,6 +810,11 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     if (pid_begin + count < pid_begin) return fail(RT_ERR_ARG, "rt_trace: photon id range overflows 64 bits");
     RT_HIP(hipSetDevice(c->device));
     if (count == 0) { c->timed = false; return RT_OK; }
+    if (c->maj_dirty)
+    {
+        const int rc = build_majorants(c);
+        if (rc != RT_OK) return rc;
+    }
 
     TraceArgs a;
     a.k_tot = c->d_k_tot; a.ssa = c->d_ssa; a.scat = c->d_scat;
@@ -593,10 +827,17 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
     a.albedo = c->albedo;
     a.sun_x = c->slabs.sun[0]; a.sun_y = c->slabs.sun[1]; a.sun_z = c->slabs.sun[2];
-    a.inv_sun_z = 1.0f / a.sun_z;
+    a.inv_sun_x = 1.0f / a.sun_x; a.inv_sun_y = 1.0f / a.sun_y; a.inv_sun_z = 1.0f / a.sun_z;
     a.nslab = c->slabs.nslab;
     for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
-    for (int i = 0; i < 3; ++i) a.inv_kmaj[i] = c->inv_kmaj[i];
+    a.maj = c->d_maj;
+    a.gslab = c->slabs.gslab;
+    a.nci = c->slabs.nci; a.ncj = c->slabs.ncj; a.nck = c->slabs.nck;
+    a.ncoarse = (uint32_t)c->ncoarse;
+    a.hx = c->slabs.hx; a.hy = c->slabs.hy; a.hz = c->slabs.hz;
+    a.inv_hx = a.gslab >= 0 ? 1.0f / a.hx : 0.0f; a.inv_hy = a.gslab >= 0 ? 1.0f / a.hy : 0.0f;
+    a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
+    a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
 
     uint64_t blocks = (count + kBlock - 1) / kBlock;
     const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
@@ -705,7 +946,29 @@ int rt_get_slabs(rt_context* c, rt_slab_info* out)
 {
     if (!c || !out) return fail(RT_ERR_ARG, "rt_get_slabs: null argument");
     if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_slabs: call rt_upload_optics first");
+    if (c->maj_dirty)
+    {
+        RT_HIP(hipSetDevice(c->device));
+        const int rc = build_majorants(c);
+        if (rc != RT_OK) return rc;
+    }
     *out = c->slabs;
+    return RT_OK;
+}
+
+int rt_get_majorants(rt_context* c, float* out_pairs, size_t n_pairs)
+{
+    if (!c || !out_pairs) return fail(RT_ERR_ARG, "rt_get_majorants: null argument");
+    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_majorants: call rt_upload_optics first");
+    RT_HIP(hipSetDevice(c->device));
+    if (c->maj_dirty)
+    {
+        const int rc = build_majorants(c);
+        if (rc != RT_OK) return rc;
+    }
+    if (n_pairs != c->ncoarse)
+        return fail(RT_ERR_ARG, "rt_get_majorants: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n_pairs);
+    if (n_pairs) RT_HIP(hipMemcpy(out_pairs, c->d_maj, sizeof(float2) * n_pairs, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

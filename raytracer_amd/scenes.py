@@ -80,7 +80,8 @@ def _mix(k_gas, ssa_gas, asy_gas, k_cloud, ssa_cloud, asy_cloud):
     sc = f(ssa_cloud) * k_cloud
     ssa = ((sg + sc) / (k_gas + k_cloud)).astype(f)
     with np.errstate(invalid="ignore", divide="ignore"):
-        asy = ((f(asy_gas) * sg + f(asy_cloud) * sc) / (sg + sc)).astype(f)
+        # association of raytracer_3d.cu:62: (asy*ssa)*k, so the float32 values match the C++ driver's
+        asy = (((f(asy_gas) * f(ssa_gas)) * k_gas + (f(asy_cloud) * f(ssa_cloud)) * k_cloud) / (sg + sc)).astype(f)
     asy = np.where(k_cloud > 0, asy, f(0)).astype(f)
     ssa = np.where(k_cloud > 0, ssa, f(ssa_gas)).astype(f)
     return ssa, asy

@@ -30,7 +30,8 @@ class RtError(RuntimeError):
 class SlabInfo(C.Structure):
     _fields_ = [("nslab", C.c_int), ("zface", C.c_float * 4), ("kmaj", C.c_float * 3),
                 ("k_lo", C.c_int), ("k_hi", C.c_int), ("cloud_min", C.c_float), ("cloud_max", C.c_float),
-                ("sun", C.c_float * 3)]
+                ("sun", C.c_float * 3), ("gslab", C.c_int), ("nci", C.c_int), ("ncj", C.c_int), ("nck", C.c_int),
+                ("hx", C.c_float), ("hy", C.c_float), ("hz", C.c_float)]
 
 
 _lib = None
@@ -64,6 +65,7 @@ def load_library():
         "rt_tally_device_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
+        "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
         "rt_get_events": (C.c_int, [vp, u64p]),
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "rt_selftest_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -186,6 +188,21 @@ class PhotonTracer:
         s = SlabInfo()
         _check(self.lib.rt_get_slabs(self._h, C.byref(s)))
         return s
+
+    def majorants(self):
+        """The majorant grid of the cloud slab as an array [nck, ncj, nci, 2] of {M, 1/M} (or None)."""
+        s = self.slabs()
+        n = s.nci * s.ncj * s.nck
+        if n == 0:
+            return None
+        out = np.zeros((s.nck, s.ncj, s.nci, 2), dtype=np.float32)
+        _check(self.lib.rt_get_majorants(self._h, _f32p(out), n))
+        return out
+
+    def set_supergrid(self, sx, sy, sz):
+        """Supervoxel size in cells of the majorant grid over the cloud slab; (0,0,0) disables it."""
+        for axis, v in zip("xyz", (sx, sy, sz)):
+            self.set_option("supergrid_" + axis, v)
 
     def tally_device_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

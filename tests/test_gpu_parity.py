@@ -85,35 +85,76 @@ def test_device_math_is_bit_identical_to_oracle(rt):
     assert np.max(np.abs(got - np.log(x))) < 2e-6
 
 
-@pytest.mark.parametrize("scene_name,n", [("tiny", 1 << 16), ("block_cloud", 1 << 19), ("rayleigh", 1 << 18),
-                                          ("rayleigh_absorbing", 1 << 18), ("cumulus_small", 1 << 18),
-                                          ("cloud_to_ground", 1 << 16), ("cloud_to_top", 1 << 16)])
-def test_tallies_bit_identical_to_oracle(rt, scene_name, n):
-    S = rt.scenes
-    scene = {
-        "tiny": lambda: S.tiny(),
-        "block_cloud": lambda: S.block_cloud(),
-        "rayleigh": lambda: S.rayleigh_column(ssa=1.0),
-        "rayleigh_absorbing": lambda: S.rayleigh_column(ssa=0.5, scale_height=8000.0),
-        "cumulus_small": lambda: S.cumulus(96, 80, 48, 50.0, 50.0, 25.0, n_clouds=12, seed=3, z_base=300.0, z_top=900.0),
-        "cloud_to_ground": lambda: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=5, z_base=0.0, z_top=300.0),
-        "cloud_to_top": lambda: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=6, z_base=300.0, z_top=600.0),
-    }[scene_name]()
-    tr = rt.PhotonTracer.from_scene(scene, stats=1)
-    sl, osl = tr.slabs(), O.oracle_slabs(scene)
+SCENES = {
+    "tiny": lambda S: S.tiny(),
+    "block_cloud": lambda S: S.block_cloud(),
+    "rayleigh": lambda S: S.rayleigh_column(ssa=1.0),
+    "rayleigh_absorbing": lambda S: S.rayleigh_column(ssa=0.5, scale_height=8000.0),
+    "cumulus_small": lambda S: S.cumulus(96, 80, 48, 50.0, 50.0, 25.0, n_clouds=12, seed=3, z_base=300.0, z_top=900.0),
+    "cloud_to_ground": lambda S: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=5, z_base=0.0, z_top=300.0),
+    "cloud_to_top": lambda S: S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=6, z_base=300.0, z_top=600.0),
+}
+
+
+def _check_structures(tr, scene, supergrid):
+    sl, osl = tr.slabs(), O.oracle_slabs(scene, supergrid=supergrid)
     assert sl.nslab == osl.nslab and list(sl.zface) == list(osl.zface) and list(sl.kmaj) == list(osl.kmaj)
     assert (sl.k_lo, sl.k_hi) == (osl.k_lo, osl.k_hi) and list(sl.sun) == list(osl.sun)
+    assert (sl.gslab, sl.nci, sl.ncj, sl.nck) == (osl.gslab, osl.nci, osl.ncj, osl.nck)
+    assert (sl.hx, sl.hy, sl.hz) == (osl.hx, osl.hy, osl.hz)
+    maj = tr.majorants()
+    if osl.maj_array is None:
+        assert maj is None
+    else:
+        assert np.array_equal(maj.view(np.uint32), osl.maj_array.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_name,n,supergrid", [
+    ("tiny", 1 << 16, (8, 8, 4)), ("tiny", 1 << 16, None), ("tiny", 1 << 16, (5, 3, 2)), ("tiny", 1 << 15, (1, 1, 1)),
+    ("block_cloud", 1 << 19, (8, 8, 4)), ("block_cloud", 1 << 18, None),
+    ("rayleigh", 1 << 18, (8, 8, 4)), ("rayleigh_absorbing", 1 << 18, (8, 8, 4)),
+    ("cumulus_small", 1 << 18, (8, 8, 4)), ("cumulus_small", 1 << 17, (16, 16, 8)), ("cumulus_small", 1 << 17, None),
+    ("cloud_to_ground", 1 << 16, (8, 8, 4)), ("cloud_to_ground", 1 << 16, (4, 4, 2)),
+    ("cloud_to_top", 1 << 16, (8, 8, 4)), ("cloud_to_top", 1 << 16, (4, 4, 1))])
+def test_tallies_bit_identical_to_oracle(rt, scene_name, n, supergrid):
+    scene = SCENES[scene_name](rt.scenes)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1)
+    tr.set_supergrid(*(supergrid or (0, 0, 0)))
+    _check_structures(tr, scene, supergrid)
     seed, begin = 1234, 10_000_000_000      # photon IDs beyond 2^32 exercise the high counter word
     tr.trace(seed, begin, n)
     tr.synchronize()
     got = tr.tallies()
-    want, ev = O.photon_oracle(scene, seed, begin, n)
+    want, ev = O.photon_oracle(scene, seed, begin, n, supergrid=supergrid)
     _assert_same(got, want)
     assert rt.photon_balance(got) == 0
     assert int(got["toa_down"].sum()) == n
-    gev = tr.events()
-    assert gev == ev
+    assert tr.events() == ev
     tr.close()
+
+
+@pytest.mark.parametrize("th_event,th_scatter,low", [(1, 1, 1), (64, 64, 64), (20, 16, 20), (8, 40, 3), (48, 4, 60)])
+def test_wave_scheduling_does_not_change_results(rt, th_event, th_scatter, low):
+    """Stage thresholds only reorder which lanes are served when; tallies must not move."""
+    scene = rt.scenes.tiny()
+    n = 1 << 16
+    tr = rt.PhotonTracer.from_scene(scene, th_event=th_event, th_scatter=th_scatter, low_traverse=low)
+    tr.trace(77, 123, n); tr.synchronize()
+    want, _ = O.photon_oracle(scene, 77, 123, n)
+    _assert_same(tr.tallies(), want)
+    tr.close()
+
+
+def test_frozen_golden_vector(rt):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "photon_oracle_tiny.npz"))
+    tr = rt.PhotonTracer.from_scene(rt.scenes.tiny(), stats=1)
+    tr.trace(11, 0, 1 << 14); tr.synchronize()
+    got = tr.tallies()
+    for name in O.TALLY_NAMES:
+        assert np.array_equal(got[name], gold[name]), name
+    ev = tr.events()
+    assert [ev[k] for k in O.EVENT_NAMES] == [int(v) for v in gold["events"]]
 
 
 def test_fixed_dot_mode_matches_oracle(rt):

@@ -37,6 +37,8 @@ def test_block_cloud_matches_reference_scene():
     assert np.array_equal(sc.k_cloud > 0, ref["k_cloud"] > 0) and int((sc.k_cloud > 0).sum()) == 20 * 20 * 20
     assert np.allclose(sc.ssa, ref["ssa"], rtol=1e-6) and np.allclose(sc.asy, ref["asy"], rtol=1e-6)
     assert sc.k_gas.dtype == np.float32 and sc.k_gas.shape == (128, 128, 128)
+    # the float32 mixing of raytracer_3d.cu:60-63 as g++ evaluates it (drivers/raytracer_3d_gpu.cpp)
+    assert float(sc.ssa.max()).hex() == "0x1.c8c8c80000000p-1" and float(sc.asy.max()).hex() == "0x1.ae6ae60000000p-1"
 
 
 def test_outputs_read_like_plot_results_3d(tmp_path):
