@@ -137,7 +137,7 @@ int rt_set_stream(rt_context* ctx, void* hip_stream);
 int rt_trace(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t photon_count);
 
 /* Blocks until the context's stream is idle (cudaDeviceSynchronize at raytracer_3d.cu:165) and
- * reports RT_ERR_ABORTED if any photon hit the step guard. */
+ * reports RT_ERR_ABORTED (once) if any photon hit the step guard since the last call. */
 int rt_synchronize(rt_context* ctx);
 
 /* Copies the seven tally arrays to caller-allocated host arrays, out[rt_tally].
@@ -148,7 +148,8 @@ int rt_download_tallies(rt_context* ctx, uint64_t* const out[RT_N_TALLIES]);
  * the host arrays up "to enable restarts later"). */
 int rt_upload_tallies(rt_context* ctx, const uint64_t* const in[RT_N_TALLIES]);
 
-/* Zeroes the device tallies and event counters. */
+/* Zeroes the device tallies and event counters (except the abort counter, which only
+ * rt_synchronize reports and clears). */
 int rt_reset_tallies(rt_context* ctx);
 
 /* The concatenated device tally buffer: 5*itot*jtot + 2*itot*jtot*ktot uint64 words in rt_tally

@@ -325,12 +325,12 @@ static inline void bump(uint64_t* p)
     ++*p;
 }
 
-/* distance along the ray (in units of the direction vector) to a face; negative (already past
- * the face by rounding) -> 0, NaN (zero direction component on the face) -> infinity */
+/* distance along the ray (in units of the direction vector) to a face; a small negative value
+ * (already past the face by rounding) -> 0; NaN or -infinity (zero direction component) -> infinity */
 static inline float face_distance(float face, float pos, float inv_u)
 {
     const float t = (face - pos) * inv_u;
-    return t >= 0.0f ? t : (t < 0.0f ? 0.0f : INFINITY);
+    return t >= 0.0f ? t : (t > -INFINITY ? 0.0f : INFINITY);
 }
 
 /* Draw layout: ONE Philox block per event, counter = (pid_lo, pid_hi, event index, 0):

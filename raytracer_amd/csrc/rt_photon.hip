@@ -85,11 +85,12 @@ __device__ __forceinline__ void tally_add(unsigned long long* p)
     __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// distance along the ray to a face; negative (past the face by rounding) -> 0, NaN -> infinity
+// distance along the ray to a face; small negative (past the face by rounding) -> 0;
+// NaN or -infinity (zero direction component) -> infinity
 __device__ __forceinline__ float face_distance(float face, float pos, float inv_u)
 {
     const float t = (face - pos) * inv_u;
-    return t >= 0.0f ? t : (t < 0.0f ? 0.0f : __builtin_inff());
+    return t >= 0.0f ? t : (t > -__builtin_inff() ? 0.0f : __builtin_inff());
 }
 
 enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5 };
@@ -869,7 +870,10 @@ int rt_synchronize(rt_context* c)
     unsigned long long aborted = 0;
     RT_HIP(hipMemcpy(&aborted, c->d_events + RT_EV_ABORT, sizeof(aborted), hipMemcpyDeviceToHost));
     if (aborted)
+    {
+        RT_HIP(hipMemset(c->d_events + RT_EV_ABORT, 0, sizeof(aborted)));
         return fail(RT_ERR_ABORTED, "rt_synchronize: %llu photons abandoned by the step guard", aborted);
+    }
     return RT_OK;
 }
 
@@ -916,7 +920,8 @@ int rt_reset_tallies(rt_context* c)
     if (!c) return fail(RT_ERR_ARG, "rt_reset_tallies: null context");
     RT_HIP(hipSetDevice(c->device));
     RT_HIP(hipMemsetAsync(c->d_tallies, 0, c->nwords * sizeof(uint64_t), c->stream));
-    RT_HIP(hipMemsetAsync(c->d_events, 0, RT_N_EVENTS * sizeof(uint64_t), c->stream));
+    // the abort counter (last word) survives a reset: rt_synchronize reports and clears it
+    RT_HIP(hipMemsetAsync(c->d_events, 0, RT_EV_ABORT * sizeof(uint64_t), c->stream));
     return RT_OK;
 }
 

@@ -202,6 +202,17 @@ def test_empty_and_single_photon_and_accumulate(rt):
     assert all(int(v.sum()) == 0 for v in tr.tallies().values())
 
 
+def test_regression_zero_direction_component(rt):
+    """Photon 31601904 of seed 0 on the block-cloud scene is reflected with an azimuth draw of
+    exactly 0 (ux == +0, 1/ux == +inf): it once crossed lateral faces forever."""
+    scene = rt.scenes.block_cloud()
+    tr = rt.PhotonTracer.from_scene(scene, stats=1)
+    tr.trace(0, 31601904, 1); tr.synchronize()
+    want, ev = O.photon_oracle(scene, 0, 31601904, 1)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev and ev["abort"] == 0 and ev["steps"] < 100
+
+
 def test_errors_are_reported_not_fatal(rt):
     with pytest.raises(rt.RtError):
         rt.PhotonTracer(0, 4, 4, 1.0, 1.0, 1.0)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Sweep scheduling thresholds / supergrid sizes / blocks per CU on one GPU (interleaved rounds in
+one process, median of kernel times). Usage: python tools/tune.py c4 24 [what]"""
+import itertools, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+what = sys.argv[3] if len(sys.argv) > 3 else "thresholds"
+scene = {"c1": rt.scenes.block_cloud, "c2": rt.scenes.rayleigh_column, "c3": rt.scenes.cumulus_c3, "c4": rt.scenes.cumulus_c4}[wl]()
+n = 1 << log2n
+tr = rt.PhotonTracer.from_scene(scene)
+
+def run(opts, rounds=3):
+    for k, v in opts.items():
+        tr.set_option(k, v)
+    ts = []
+    for r in range(rounds):
+        tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
+    return statistics.median(ts)
+
+base = dict(th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+run(base, 1)
+res = []
+if what == "thresholds":
+    for te, ts_, lo in itertools.product((8, 16, 24, 32, 48), (8, 16, 24, 32), (8, 16, 32)):
+        o = dict(base, th_event=te, th_scatter=ts_, low_traverse=lo); res.append((run(o), te, ts_, lo))
+elif what == "grid":
+    for sg in ((0, 0, 0), (4, 4, 2), (4, 4, 4), (8, 8, 2), (8, 8, 4), (8, 8, 8), (16, 16, 4), (16, 16, 8), (32, 32, 8), (2, 2, 2)):
+        o = dict(base, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2]); res.append((run(o),) + sg)
+elif what == "blocks":
+    for b in (2, 3, 4, 5, 6, 7, 8, 10, 12):
+        o = dict(base, blocks_per_cu=b); res.append((run(o), b))
+res.sort()
+for r in res[:12]:
+    print(wl, what, "ms=%.3f" % r[0], "Gph/s=%.3f" % (n / r[0] / 1e6), r[1:])
+print("worst", res[-1])
