@@ -121,6 +121,9 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change)
+ *   "pool"           photons each wave keeps in LDS (64, 96, 128, 160, 192 or 256) and compacts by
+ *                    stage into full waves; 0 = photon state stays in the lane's registers
+ *                    (scheduling only: results do not change). "pool_waves_per_cu" caps residency.
  *   "blocks_per_cu"  workgroups of 256 lanes per compute unit of the persistent launch (default 6)
  *   "stats"          1: rt_trace also counts events (rt_get_events); 0 (default): it does not */
 int rt_set_option(rt_context* ctx, const char* name, long long value);
@@ -172,6 +175,11 @@ int rt_get_majorants(rt_context* ctx, float* out_pairs, size_t n_pairs);
 /* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
  * but RT_EV_ABORT). Synchronises first. */
 int rt_get_events(rt_context* ctx, uint64_t out[RT_N_EVENTS]);
+
+/* Wave-scheduling statistics of "stats" launches since the last reset: rounds run and lanes
+ * served per stage {T rounds, E rounds, S rounds, T lanes, E lanes, S lanes}. Diagnostic only. */
+#define RT_N_SCHED 6
+int rt_get_sched_stats(rt_context* ctx, uint64_t out[RT_N_SCHED]);
 
 /* Device time of the most recent rt_trace launch in milliseconds (HIP events recorded on the
  * context's stream around the kernel; synchronises on the stop event). Mirrors the timer of

@@ -93,7 +93,7 @@ __device__ __forceinline__ float face_distance(float face, float pos, float inv_
     return t >= 0.0f ? t : (t > -__builtin_inff() ? 0.0f : __builtin_inff());
 }
 
-enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5 };
+enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5, ST_REFLECT = 6 };
 
 // ------------------------------------------------------------------------------------------
 // The photon life cycle. One lane = one photon at a time, all photon state in VGPRs.
@@ -131,6 +131,8 @@ rt_trace_kernel(const TraceArgs a)
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
+    // wave-level scheduling statistics (STATS builds): rounds and served lanes per stage
+    uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0;
 
     for (;;)
     {
@@ -138,52 +140,68 @@ rt_trace_kernel(const TraceArgs a)
             state = ST_DONE;
         const int nT = __popcll(__ballot(state == ST_TRAVERSE));
         const int nE = __popcll(__ballot(state == ST_LAUNCH || state == ST_COLLIDE || state == ST_SURFACE));
-        const int nS = __popcll(__ballot(state == ST_SCATTER));
+        const int nS = __popcll(__ballot(state == ST_SCATTER || state == ST_REFLECT));
         if (nT + nE + nS == 0)
             break;
         const bool starving = nT < a.low_traverse;
         const bool runS = nS >= a.th_scatter || (starving && nS > 0 && nS >= nE);
         const bool runE = !runS && (nE >= a.th_event || (starving && nE > 0));
+        if (STATS)
+        {
+            if (runS) { ++rounds_s; lanes_s += nS; }
+            else if (runE) { ++rounds_e; lanes_e += nE; }
+            else { ++rounds_t; lanes_t += nT; }
+        }
 
         if (runS)
         {
-            if (state == ST_SCATTER)
+            if (state == ST_SCATTER || state == ST_REFLECT)
             {
-                // phase function + rotation, raytracer_kernels.cu:520-548
-                const float2 ak = a.scat[cell];                 // {asy, k_cloud}
-                const bool from_cloud = sc_lhs < sc_s * ak.y;   // r/s < k_cloud/k_tot
-                if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                const float mu = from_cloud ? henyey_mu(ak.x, sc_umu) : rayleigh_mu(sc_umu);
-                // |mu| can come out a few ulp above 1 in float: clamp the radicand (the reference
-                // would produce a NaN direction here, raytracer_kernels.cu:523)
-                const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
-
-                float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
-                if (fx < fy)
+                float sp, cp;
+                rt_sincos2pi(sc_uphi, sp, cp);          // azimuth of the new direction, both cases
+                if (state == ST_SCATTER)
                 {
-                    if (fx < fz) ax = 1.0f; else az = 1.0f;
+                    // phase function + rotation, raytracer_kernels.cu:520-548
+                    const float2 ak = a.scat[cell];                 // {asy, k_cloud}
+                    const bool from_cloud = sc_lhs < sc_s * ak.y;   // r/s < k_cloud/k_tot
+                    if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                    const float mu = from_cloud ? henyey_mu(ak.x, sc_umu) : rayleigh_mu(sc_umu);
+                    // |mu| can come out a few ulp above 1 in float: clamp the radicand (the reference
+                    // would produce a NaN direction here, raytracer_kernels.cu:523)
+                    const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
+
+                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                    const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
+                    if (fx < fy)
+                    {
+                        if (fx < fz) ax = 1.0f; else az = 1.0f;
+                    }
+                    else
+                    {
+                        if (fy < fz) ay = 1.0f; else az = 1.0f;
+                    }
+                    // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
+                    const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
+                                                 : fma_(az, az, fma_(ay, uy, ax * ux));
+                    float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
+                    const float inv_len = 1.0f / __builtin_sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
+                    ox *= inv_len; oy *= inv_len; oz *= inv_len;
+                    const float bx = fma_(uy, oz, -(uz * oy));
+                    const float by = fma_(uz, ox, -(ux * oz));
+                    const float bz = fma_(ux, oy, -(uy * ox));
+                    const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
+                    const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
+                    const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
+                    ux = nx; uy = ny; uz = nz;
                 }
                 else
                 {
-                    if (fy < fz) ay = 1.0f; else az = 1.0f;
+                    // Lambertian reflection, raytracer_kernels.cu:467-473
+                    const float mu = __builtin_sqrtf(sc_umu);
+                    ux = mu * sp;
+                    uy = mu * cp;
+                    uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
-                // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
-                const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
-                                             : fma_(az, az, fma_(ay, uy, ax * ux));
-                float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
-                const float inv_len = 1.0f / __builtin_sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
-                ox *= inv_len; oy *= inv_len; oz *= inv_len;
-                const float bx = fma_(uy, oz, -(uz * oy));
-                const float by = fma_(uz, ox, -(ux * oz));
-                const float bz = fma_(ux, oy, -(uy * ox));
-
-                float sp, cp;
-                rt_sincos2pi(sc_uphi, sp, cp);
-                const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
-                const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
-                const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
-                ux = nx; uy = ny; uz = nz;
                 iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
                 diffuse = true;
                 state = ST_TRAVERSE;
@@ -211,14 +229,16 @@ rt_trace_kernel(const TraceArgs a)
                 }
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
                 ++nev;
+                // the optical depth to the next collision: third word at launch, second otherwise
+                float tau_new = free_path_tau(u01(state == ST_LAUNCH ? w.z : w.y));
+                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
 
                 if (state == ST_LAUNCH)
                 {
                     // launch at the top of the domain, raytracer_kernels.cu:180-208
                     x = a.xs * u01(w.x);
                     y = a.ys * u01(w.y);
-                    tau = free_path_tau(u01(w.z));
-                    tau = tau > 0.0f ? tau : 0.0f;
+                    tau = tau_new;
                     z = ztop;
                     ux = a.sun_x; uy = a.sun_y; uz = a.sun_z;
                     iux = a.inv_sun_x; iuy = a.inv_sun_y; iuz = a.inv_sun_z;
@@ -240,6 +260,8 @@ rt_trace_kernel(const TraceArgs a)
                     const float r = u01(w.x);
                     const float p_real = kt * inv_m;
                     state = ST_TRAVERSE;
+                    // null collision or scattering: the photon goes on with a fresh optical depth
+                    tau = tau_new;
                     if (r < p_real)
                     {
                         if (STATS) ++ev_real;
@@ -257,27 +279,16 @@ rt_trace_kernel(const TraceArgs a)
                             state = ST_LAUNCH;
                         }
                     }
-                    // null collision or scattering: the photon goes on with a fresh optical depth
-                    tau = free_path_tau(u01(w.y));
-                    tau = tau > 0.0f ? tau : 0.0f;
                 }
                 else
                 {
-                    // surface: absorb or reflect (Lambertian), raytracer_kernels.cu:463-486
-                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                    const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                    // surface: absorb or reflect, raytracer_kernels.cu:463-486 (cell = column here);
+                    // the new direction is computed in stage S
                     if (u01(w.x) <= a.albedo)
                     {
-                        tally_add(&a.tallies[4u * a.ncol + ij]);
-                        const float mu = __builtin_sqrtf(u01(w.y));
-                        float sa, ca;
-                        rt_sincos2pi(u01(w.z), sa, ca);
-                        ux = mu * sa;
-                        uy = mu * ca;
-                        uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
-                        iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
-                        diffuse = true;
-                        state = ST_TRAVERSE;
+                        tally_add(&a.tallies[4u * a.ncol + cell]);
+                        sc_umu = u01(w.y); sc_uphi = u01(w.z);
+                        state = ST_REFLECT;
                     }
                     else
                         state = ST_LAUNCH;
@@ -301,16 +312,16 @@ rt_trace_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
-                    const float xlo = (float)ci * a.hx, xhi = (ci + 1 == a.nci) ? a.xs : (float)(ci + 1) * a.hx;
-                    const float ylo = (float)cj * a.hy, yhi = (cj + 1 == a.ncj) ? a.ys : (float)(cj + 1) * a.hy;
-                    const float fx = ux > 0.0f ? xhi : xlo, fy = uy > 0.0f ? yhi : ylo;
+                    // the face ahead on each axis: index of the cell face, then its coordinate
+                    const int cfx = ci + (ux > 0.0f ? 1 : 0), cfy = cj + (uy > 0.0f ? 1 : 0);
+                    const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
+                    const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
                     const bool up = uz > 0.0f;
                     float fz;
                     if (gridded)
                     {
-                        const float zlo = fma_((float)ck, a.hz, a.zc0);
-                        const float zhi = (ck + 1 == a.nck) ? a.zc1 : fma_((float)(ck + 1), a.hz, a.zc0);
-                        fz = up ? zhi : zlo;
+                        const int cfz = ck + (up ? 1 : 0);
+                        fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0);
                     }
                     else
                     {
@@ -376,7 +387,8 @@ rt_trace_kernel(const TraceArgs a)
                                 // surface arrival, raytracer_kernels.cu:455-460; the albedo draw is stage E
                                 if (STATS) ++ev_sfc;
                                 const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + (uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                                cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + cell]);
                                 state = ST_SURFACE;
                             }
                             else
@@ -405,6 +417,415 @@ rt_trace_kernel(const TraceArgs a)
             if (ev[e])
                 __hip_atomic_fetch_add(&a.events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+        if ((threadIdx.x & 63) == 0)
+        {
+            const uint32_t sch[6] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s};
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                __hip_atomic_fetch_add(&a.events[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pool variant of the tracer: every wave keeps NS (> 64) photons in LDS and, each round, gathers
+// up to 64 of them that wait for the SAME stage into its lanes (ballot + rank compaction). The
+// three stages and all per-photon arithmetic are those of rt_trace_kernel above; only where the
+// photon state lives between rounds differs, so results are bit-identical. With 2-3 photons per
+// lane in the pool, a round almost always finds a full wave of work for one stage (the lane-
+// resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
+// One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
+//
+// LDS per wave: NS records of 16 dwords (AoS, moved as 16-byte groups), NS state words and a
+// 64-entry selection list:
+//   g0 {x, y, z, tau}
+//   g1 {ux, uy, uz, nstep}
+//   g2 {1/ux, 1/uy, 1/uz, w}   w = 1/M of the region (traverse -> collision) or the surface column
+//                              (traverse -> surface event). While a photon waits for stage S the
+//                              group holds {asy, u_mu, u_phi, -}: the reciprocals are dead then.
+//   g3 {ci | cj << 16, ck | slab << 16 | diffuse << 24 | from_cloud << 25, pid_lo, pid_hi | nev << 8}
+enum : uint32_t { PS_TRAVERSE = 0, PS_LAUNCH = 4, PS_COLLIDE = 5, PS_SURFACE = 6, PS_SCATTER = 8, PS_REFLECT = 9, PS_DONE = 12 };
+constexpr int kPoolRec = 16;
+constexpr int kPoolBlock = 64;
+
+template <bool FIXED_DOT, bool STATS, int NS>
+__global__ void __launch_bounds__(kPoolBlock)
+rt_trace_pool_kernel(const TraceArgs a)
+{
+    using namespace rt;
+    static_assert(NS % 32 == 0 && NS >= 64 && NS <= 256, "pool size");
+    constexpr int kHalves = (NS + 63) / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + kHalves * 64 + 64];
+
+    const int lane = threadIdx.x;
+    uint32_t* const rec = lds;                                  // NS records
+    uint32_t* const st = rec + NS * kPoolRec;                   // state words (padded to kHalves*64)
+    uint32_t* const sel = st + kHalves * 64;                    // 64 selected slots
+
+    // contiguous photon-ID range of this wave
+    const uint64_t nwaves = gridDim.x;
+    const uint64_t wave_id = blockIdx.x;
+    const uint64_t total = a.pid_end - a.pid_begin;
+    const uint64_t per_wave = (total + nwaves - 1) / nwaves;
+    uint64_t wave_next = a.pid_begin + (wave_id * per_wave < total ? wave_id * per_wave : total);
+    const uint64_t wave_end = a.pid_begin + ((wave_id + 1) * per_wave < total ? (wave_id + 1) * per_wave : total);
+
+    const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
+    const float ztop = a.zface[a.nslab];
+
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h)
+        st[h * 64 + lane] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
+    int n_t = 0, n_e = NS, n_s = 0;      // photons waiting per stage (wave-uniform)
+
+    uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
+             ev_abs = 0, ev_trans = 0;
+    uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0;
+
+    while (n_t + n_e + n_s > 0)
+    {
+        // serve the stage with the most photons waiting (ties: traverse, then event)
+        const uint32_t cls = (n_t >= n_e && n_t >= n_s) ? 0u : (n_e >= n_s ? 1u : 2u);
+
+        // ---- gather up to 64 waiting slots into the lanes ----
+        asm volatile("" ::: "memory");
+        int found = 0;
+#pragma unroll
+        for (int h = 0; h < kHalves; ++h)
+        {
+            const uint32_t sidx = h * 64 + lane;
+            const bool match = (st[sidx] >> 2) == cls;
+            const unsigned long long m = __ballot(match);
+            const int rank = found + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (match && rank < 64)
+                sel[rank] = sidx;
+            found += __popcll(m);
+        }
+        asm volatile("" ::: "memory");
+        const int n = found < 64 ? found : 64;
+        const bool active = lane < n;
+        const uint32_t slot = active ? sel[lane] : 0u;
+        uint32_t* const r = rec + slot * kPoolRec;
+        float4* const r4 = reinterpret_cast<float4*>(r);
+        uint32_t ns = PS_DONE;           // new state of the photon this lane serves
+
+        if (cls == 2u)
+        {
+            if (STATS) { ++rounds_s; lanes_s += n; }
+            if (active)
+            {
+                const uint32_t state = st[slot];
+                const float4 g1 = r4[1];
+                const float4 g2 = r4[2];                     // {asy, u_mu, u_phi, -}
+                const uint32_t cks = r[13];
+                float ux = g1.x, uy = g1.y, uz = g1.z;
+                float sp, cp;
+                rt_sincos2pi(g2.z, sp, cp);
+                if (state == PS_SCATTER)
+                {
+                    // phase function + rotation, raytracer_kernels.cu:520-548
+                    const bool from_cloud = (cks >> 25) & 1u;
+                    const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
+                    const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
+                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                    const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
+                    if (fx < fy)
+                    {
+                        if (fx < fz) ax = 1.0f; else az = 1.0f;
+                    }
+                    else
+                    {
+                        if (fy < fz) ay = 1.0f; else az = 1.0f;
+                    }
+                    // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
+                    const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
+                                                 : fma_(az, az, fma_(ay, uy, ax * ux));
+                    float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
+                    const float inv_len = 1.0f / __builtin_sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
+                    ox *= inv_len; oy *= inv_len; oz *= inv_len;
+                    const float bx = fma_(uy, oz, -(uz * oy));
+                    const float by = fma_(uz, ox, -(ux * oz));
+                    const float bz = fma_(ux, oy, -(uy * ox));
+                    const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
+                    const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
+                    const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
+                    ux = nx; uy = ny; uz = nz;
+                }
+                else
+                {
+                    // Lambertian reflection, raytracer_kernels.cu:467-473
+                    const float mu = __builtin_sqrtf(g2.y);
+                    ux = mu * sp;
+                    uy = mu * cp;
+                    uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+                }
+                r4[1] = make_float4(ux, uy, uz, g1.w);
+                r4[2] = make_float4(1.0f / ux, 1.0f / uy, 1.0f / uz, 0.0f);
+                r[13] = (cks | (1u << 24)) & ~(1u << 25);      // diffuse from now on
+                ns = PS_TRAVERSE;
+            }
+        }
+        else if (cls == 1u)
+        {
+            if (STATS) { ++rounds_e; lanes_e += n; }
+            // photon IDs for the launching lanes of this round
+            const uint32_t state = active ? st[slot] : PS_DONE;
+            const unsigned long long ml = __ballot(state == PS_LAUNCH);
+            const uint64_t my_pid = wave_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u));
+            wave_next += __popcll(ml);
+            if (active && !(state == PS_LAUNCH && my_pid >= wave_end))
+            {
+                uint32_t pid_lo, pid_hi, nev, cell = 0, cks = 0;
+                float kt = 0.0f, inv_m = 0.0f;
+                if (state == PS_LAUNCH)
+                {
+                    pid_lo = (uint32_t)my_pid; pid_hi = (uint32_t)(my_pid >> 32); nev = 0;
+                }
+                else
+                {
+                    pid_lo = r[14];
+                    const uint32_t pn = r[15];
+                    pid_hi = pn & 0xffu; nev = pn >> 8;
+                    cks = r[13];
+                    const uint32_t w11 = r[11];
+                    if (state == PS_COLLIDE)
+                    {
+                        const float4 g0 = r4[0];
+                        inv_m = __uint_as_float(w11);
+                        const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
+                        const int k = cell_of(g0.z, a.inv_dz, a.ktot);
+                        cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
+                        kt = a.k_tot[cell];
+                    }
+                    else
+                        cell = w11;          // surface column stored by the traverse stage
+                }
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
+                ++nev;
+                float tau_new = free_path_tau(u01(state == PS_LAUNCH ? w.z : w.y));
+                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
+
+                if (state == PS_LAUNCH)
+                {
+                    // launch at the top of the domain, raytracer_kernels.cu:180-208
+                    const float x = a.xs * u01(w.x), y = a.ys * u01(w.y);
+                    const int slab = a.nslab - 1;
+                    int ci = 0, cj = 0, ck = 0;
+                    if (slab == a.gslab)
+                    {
+                        ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
+                    }
+                    r4[0] = make_float4(x, y, ztop, tau_new);
+                    r4[1] = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
+                    r4[2] = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
+                    r[12] = (uint32_t)ci | ((uint32_t)cj << 16);
+                    r[13] = (uint32_t)ck | ((uint32_t)slab << 16);
+                    r[14] = pid_lo; r[15] = pid_hi | (nev << 8);
+                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                    tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                    ns = PS_TRAVERSE;
+                }
+                else if (state == PS_COLLIDE)
+                {
+                    // collision classification, raytracer_kernels.cu:507-518
+                    if (STATS) ++ev_coll;
+                    const float rr = u01(w.x);
+                    const float p_real = kt * inv_m;
+                    ns = PS_TRAVERSE;
+                    r[3] = __float_as_uint(tau_new);
+                    r[15] = pid_hi | (nev << 8);
+                    if (rr < p_real)
+                    {
+                        if (STATS) ++ev_real;
+                        const float s_scat = a.ssa[cell] * p_real;
+                        if (rr <= s_scat)
+                        {
+                            const float2 ak = a.scat[cell];                    // {asy, k_cloud}
+                            const bool from_cloud = rr * kt < s_scat * ak.y;   // r/s < k_cloud/k_tot
+                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                            r4[2] = make_float4(ak.x, u01(w.z), u01(w.w), 0.0f);
+                            r[13] = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
+                            ns = PS_SCATTER;
+                        }
+                        else
+                        {
+                            // absorption, raytracer_kernels.cu:551-566
+                            if (STATS) ++ev_abs;
+                            const bool diffuse = (cks >> 24) & 1u;
+                            tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncell : 0u) + cell]);
+                            ns = PS_LAUNCH;
+                        }
+                    }
+                }
+                else
+                {
+                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
+                    r[15] = pid_hi | (nev << 8);
+                    if (u01(w.x) <= a.albedo)
+                    {
+                        tally_add(&a.tallies[4u * a.ncol + cell]);
+                        r[9] = __float_as_uint(u01(w.y)); r[10] = __float_as_uint(u01(w.z));
+                        ns = PS_REFLECT;
+                    }
+                    else
+                        ns = PS_LAUNCH;
+                }
+            }
+        }
+        else
+        {
+            if (STATS) { ++rounds_t; lanes_t += n; }
+            if (active)
+            {
+                const float4 g0 = r4[0];
+                const float4 g1 = r4[1];
+                const float4 g2 = r4[2];
+                const uint32_t cicj = r[12], cks = r[13];
+                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
+                const float ux = g1.x, uy = g1.y, uz = g1.z;
+                uint32_t nstep = __float_as_uint(g1.w);
+                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
+                int slab = (int)((cks >> 16) & 0xffu);
+                const bool diffuse = (cks >> 24) & 1u;
+                ns = PS_TRAVERSE;
+                if (nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
+                {
+                    tally_add(&a.events[RT_EV_ABORT]);
+                    ns = PS_LAUNCH;
+                }
+                else
+                {
+                    ++nstep;
+                    if (STATS) ++ev_step;
+                    // ---- cross one majorant region or stop at the collision site ----
+                    const bool gridded = slab == a.gslab;
+                    const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
+                    const float2 mm = a.maj[e];
+                    const int cfx = ci + (ux > 0.0f ? 1 : 0), cfy = cj + (uy > 0.0f ? 1 : 0);
+                    const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
+                    const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
+                    const bool up = uz > 0.0f;
+                    float fz;
+                    if (gridded)
+                    {
+                        const int cfz = ck + (up ? 1 : 0);
+                        fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0);
+                    }
+                    else
+                    {
+                        const int fi = up ? slab + 1 : slab;
+                        fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3]));
+                    }
+                    const float tx = gridded ? face_distance(fx, x, g2.x) : __builtin_inff();
+                    const float ty = gridded ? face_distance(fy, y, g2.y) : __builtin_inff();
+                    const float tz = face_distance(fz, z, g2.z);
+                    float t_exit = tx; int axis = 0;
+                    if (ty < t_exit) { t_exit = ty; axis = 1; }
+                    if (tz < t_exit) { t_exit = tz; axis = 2; }
+                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff();   // raytracer_kernels.cu:367
+                    const bool hit = t_exit <= dn;
+                    const float tt = hit ? t_exit : dn;
+                    x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
+                    if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
+                    uint32_t w11 = __float_as_uint(mm.y);
+
+                    if (!hit)
+                        ns = PS_COLLIDE;
+                    else
+                    {
+                        if (STATS) ++ev_trans;
+                        tau = fma_(-tt, mm.x, tau);
+                        tau = tau > 0.0f ? tau : 0.0f;
+                        int leave = 0;
+                        if (axis == 0)
+                        {
+                            x = fx; ci += ux > 0.0f ? 1 : -1;
+                            if (ci == a.nci) { ci = 0; x = 0.0f; }
+                            if (ci < 0) { ci = a.nci - 1; x = a.xs; }
+                        }
+                        else if (axis == 1)
+                        {
+                            y = fy; cj += uy > 0.0f ? 1 : -1;
+                            if (cj == a.ncj) { cj = 0; y = 0.0f; }
+                            if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
+                        }
+                        else
+                        {
+                            z = fz;
+                            if (gridded)
+                            {
+                                const int nk = ck + (up ? 1 : -1);
+                                if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1;
+                            }
+                            else
+                                leave = up ? 1 : -1;
+                        }
+                        if (leave != 0)
+                        {
+                            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                            const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                            if (leave > 0 && slab == a.nslab - 1)
+                            {
+                                // top of the atmosphere, raytracer_kernels.cu:487-499
+                                if (STATS) ++ev_toa;
+                                tally_add(&a.tallies[a.ncol + ij]);
+                                ns = PS_LAUNCH;
+                            }
+                            else if (leave < 0 && slab == 0)
+                            {
+                                // surface arrival, raytracer_kernels.cu:455-460
+                                if (STATS) ++ev_sfc;
+                                w11 = ij;
+                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]);
+                                ns = PS_SURFACE;
+                            }
+                            else
+                            {
+                                // next slab, raytracer_kernels.cu:376-415
+                                slab += leave;
+                                if (slab == a.gslab)
+                                {
+                                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj);
+                                    ck = leave > 0 ? 0 : a.nck - 1;
+                                }
+                            }
+                        }
+                    }
+                    r4[0] = make_float4(x, y, z, tau);
+                    r[7] = nstep;
+                    r[11] = w11;
+                    r[12] = (uint32_t)ci | ((uint32_t)cj << 16);
+                    r[13] = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
+                }
+            }
+        }
+
+        // ---- publish the new states and update the stage counts ----
+        if (active)
+            st[slot] = ns;
+        const uint32_t ncls = active ? (ns >> 2) : 3u;
+        const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)), d_s = __popcll(__ballot(ncls == 2u));
+        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else n_s -= n;
+        n_t += d_t; n_e += d_e; n_s += d_s;
+    }
+
+    if (STATS)
+    {
+        const uint32_t ev[9] = {ev_step, ev_coll, ev_real, ev_scat, ev_cscat, ev_sfc, ev_toa, ev_abs, ev_trans};
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+            if (ev[e])
+                __hip_atomic_fetch_add(&a.events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+        {
+            const uint32_t sch[6] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s};
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                __hip_atomic_fetch_add(&a.events[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -532,6 +953,8 @@ struct rt_context
     bool maj_dirty = true;
     int sgx = 8, sgy = 8, sgz = 4;    // supervoxel size in cells (0 = no grid, slabs only)
     int th_event = 20, th_scatter = 16, low_traverse = 20;
+    int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
+    int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
@@ -697,9 +1120,9 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
     if (e == hipSuccess) e = hipMalloc(&c->d_ssa, sizeof(float) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_scat, sizeof(float2) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
-    if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * RT_N_EVENTS);
+    if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * (RT_N_EVENTS + RT_N_SCHED));
     if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
-    if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * RT_N_EVENTS);
+    if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * (RT_N_EVENTS + RT_N_SCHED));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e != hipSuccess)
@@ -781,6 +1204,17 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value < 1 || value > 16) return fail(RT_ERR_ARG, "rt_set_option: blocks_per_cu %lld outside [1,16]", value);
         c->blocks_per_cu = (int)value;
     }
+    else if (!strcmp(name, "pool"))
+    {
+        if (value != 0 && value != 64 && value != 96 && value != 128 && value != 160 && value != 192 && value != 256)
+            return fail(RT_ERR_ARG, "rt_set_option: pool %lld not one of 0, 64, 96, 128, 160, 192, 256", value);
+        c->pool = (int)value;
+    }
+    else if (!strcmp(name, "pool_waves_per_cu"))
+    {
+        if (value < 1 || value > 32) return fail(RT_ERR_ARG, "rt_set_option: pool_waves_per_cu %lld outside [1,32]", value);
+        c->pool_waves_per_cu = (int)value;
+    }
     else if (!strcmp(name, "supergrid_x") || !strcmp(name, "supergrid_y") || !strcmp(name, "supergrid_z"))
     {
         if (value < 0 || value > 4096) return fail(RT_ERR_ARG, "rt_set_option: %s %lld outside [0,4096]", name, value);
@@ -845,16 +1279,52 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     if (blocks > cap) blocks = cap;
 
     RT_HIP(hipEventRecord(c->ev_start, c->stream));
-    const dim3 grid((unsigned)blocks), block(kBlock);
-    if (c->fixed_dot)
+    const dim3 block(kBlock);
+    if (c->pool > 0)
     {
-        if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
+        // pool kernel: one wave per workgroup; LDS bounds the resident waves (160 KiB per CU)
+        const int ns = c->pool;
+        if (a.pid_end > (1ull << 40))
+            return fail(RT_ERR_ARG, "rt_trace: the pool kernel packs photon ids into 40 bits");
+        const size_t lds_bytes = ((size_t)ns * kPoolRec + (size_t)((ns + 63) / 64) * 64 + 64) * 4;
+        int per_cu = (int)((160u * 1024u) / lds_bytes);
+        if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t pblocks = (count + (uint64_t)ns - 1) / (uint64_t)ns;
+        const uint64_t pcap = (uint64_t)c->cu_count * per_cu;
+        if (pblocks > pcap) pblocks = pcap;
+        const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
+#define RT_LAUNCH_POOL(NS)                                                                                         \
+        do {                                                                                                       \
+            if (c->fixed_dot) { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<true, true, NS>), grid, pblock, 0, c->stream, a);   \
+                                else hipLaunchKernelGGL((rt_trace_pool_kernel<true, false, NS>), grid, pblock, 0, c->stream, a); }        \
+            else { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<false, true, NS>), grid, pblock, 0, c->stream, a);              \
+                   else hipLaunchKernelGGL((rt_trace_pool_kernel<false, false, NS>), grid, pblock, 0, c->stream, a); }                    \
+        } while (0)
+        switch (ns)
+        {
+            case 64: RT_LAUNCH_POOL(64); break;
+            case 96: RT_LAUNCH_POOL(96); break;
+            case 128: RT_LAUNCH_POOL(128); break;
+            case 160: RT_LAUNCH_POOL(160); break;
+            case 192: RT_LAUNCH_POOL(192); break;
+            default: RT_LAUNCH_POOL(256); break;
+        }
+#undef RT_LAUNCH_POOL
     }
     else
     {
-        if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+        const dim3 grid((unsigned)blocks);
+        if (c->fixed_dot)
+        {
+            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
+            else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
+        }
+        else
+        {
+            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
+            else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+        }
     }
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(c->ev_stop, c->stream));
@@ -922,6 +1392,7 @@ int rt_reset_tallies(rt_context* c)
     RT_HIP(hipMemsetAsync(c->d_tallies, 0, c->nwords * sizeof(uint64_t), c->stream));
     // the abort counter (last word) survives a reset: rt_synchronize reports and clears it
     RT_HIP(hipMemsetAsync(c->d_events, 0, RT_EV_ABORT * sizeof(uint64_t), c->stream));
+    RT_HIP(hipMemsetAsync(c->d_events + RT_N_EVENTS, 0, RT_N_SCHED * sizeof(uint64_t), c->stream));
     return RT_OK;
 }
 
@@ -983,6 +1454,15 @@ int rt_get_events(rt_context* c, uint64_t out[RT_N_EVENTS])
     RT_HIP(hipSetDevice(c->device));
     RT_HIP(hipStreamSynchronize(c->stream));
     RT_HIP(hipMemcpy(out, c->d_events, RT_N_EVENTS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_sched_stats(rt_context* c, uint64_t out[RT_N_SCHED])
+{
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_sched_stats: null argument");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipStreamSynchronize(c->stream));
+    RT_HIP(hipMemcpy(out, c->d_events + RT_N_EVENTS, RT_N_SCHED * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -67,6 +67,7 @@ def load_library():
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
         "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
         "rt_get_events": (C.c_int, [vp, u64p]),
+        "rt_get_sched_stats": (C.c_int, [vp, u64p]),
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "rt_selftest_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "rt_selftest_math": (C.c_int, [C.c_int, C.c_int, f32p, C.c_size_t, f32p]),
@@ -183,6 +184,13 @@ class PhotonTracer:
         ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
         _check(self.lib.rt_get_events(self._h, ev.ctypes.data_as(C.POINTER(C.c_uint64))))
         return dict(zip(EVENT_NAMES, (int(v) for v in ev)))
+
+    def sched_stats(self):
+        """Rounds and served lanes per stage of the wave scheduler (stats launches only)."""
+        v = np.zeros(6, dtype=np.uint64)
+        _check(self.lib.rt_get_sched_stats(self._h, v.ctypes.data_as(C.POINTER(C.c_uint64))))
+        r = [int(x) for x in v]
+        return {"rounds": dict(T=r[0], E=r[1], S=r[2]), "lanes": dict(T=r[3], E=r[4], S=r[5])}
 
     def slabs(self):
         s = SlabInfo()

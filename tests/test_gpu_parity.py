@@ -117,8 +117,9 @@ def _check_structures(tr, scene, supergrid):
     ("cloud_to_ground", 1 << 16, (8, 8, 4)), ("cloud_to_ground", 1 << 16, (4, 4, 2)),
     ("cloud_to_top", 1 << 16, (8, 8, 4)), ("cloud_to_top", 1 << 16, (4, 4, 1))])
 def test_tallies_bit_identical_to_oracle(rt, scene_name, n, supergrid):
+    """Lane-resident kernel (option pool = 0); the default pool kernel has its own test below."""
     scene = SCENES[scene_name](rt.scenes)
-    tr = rt.PhotonTracer.from_scene(scene, stats=1)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=0)
     tr.set_supergrid(*(supergrid or (0, 0, 0)))
     _check_structures(tr, scene, supergrid)
     seed, begin = 1234, 10_000_000_000      # photon IDs beyond 2^32 exercise the high counter word
@@ -138,10 +139,28 @@ def test_wave_scheduling_does_not_change_results(rt, th_event, th_scatter, low):
     """Stage thresholds only reorder which lanes are served when; tallies must not move."""
     scene = rt.scenes.tiny()
     n = 1 << 16
-    tr = rt.PhotonTracer.from_scene(scene, th_event=th_event, th_scatter=th_scatter, low_traverse=low)
+    tr = rt.PhotonTracer.from_scene(scene, pool=0, th_event=th_event, th_scatter=th_scatter, low_traverse=low)
     tr.trace(77, 123, n); tr.synchronize()
     want, _ = O.photon_oracle(scene, 77, 123, n)
     _assert_same(tr.tallies(), want)
+    tr.close()
+
+
+@pytest.mark.parametrize("pool", [64, 96, 128, 160, 256])
+@pytest.mark.parametrize("scene_name,n,supergrid", [("tiny", 1 << 16, (8, 8, 4)), ("tiny", 1 << 15, (5, 3, 2)), ("tiny", 100, None),
+                                                    ("block_cloud", 1 << 18, (8, 8, 4)), ("cumulus_small", 1 << 17, (8, 8, 4)),
+                                                    ("rayleigh", 1 << 17, (8, 8, 4)), ("cloud_to_ground", 1 << 15, (4, 4, 2)),
+                                                    ("cloud_to_top", 1 << 15, (4, 4, 1))])
+def test_pool_kernel_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid):
+    """The LDS-pool kernel (photons compacted by stage into full waves) against the oracle."""
+    scene = SCENES[scene_name](rt.scenes)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool)
+    tr.set_supergrid(*(supergrid or (0, 0, 0)))
+    tr.trace(4321, 7_000_000_000, n)
+    tr.synchronize()
+    want, ev = O.photon_oracle(scene, 4321, 7_000_000_000, n, supergrid=supergrid)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev
     tr.close()
 
 

@@ -20,7 +20,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=0, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
 run(base, 1)
 res = []
 if what == "thresholds":
@@ -29,6 +29,9 @@ if what == "thresholds":
 elif what == "grid":
     for sg in ((0, 0, 0), (4, 4, 2), (4, 4, 4), (8, 8, 2), (8, 8, 4), (8, 8, 8), (16, 16, 4), (16, 16, 8), (32, 32, 8), (2, 2, 2)):
         o = dict(base, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2]); res.append((run(o),) + sg)
+elif what == "pool":
+    for pl, b in ((0, 32), (64, 32), (64, 24), (96, 32), (96, 20), (96, 16), (128, 32), (128, 16), (128, 12), (160, 32), (160, 12), (192, 32), (256, 32)):
+        o = dict(base, pool=pl, pool_waves_per_cu=b); res.append((run(o), pl, b))
 elif what == "blocks":
     for b in (2, 3, 4, 5, 6, 7, 8, 10, 12):
         o = dict(base, blocks_per_cu=b); res.append((run(o), b))
