@@ -60,15 +60,14 @@ def cpu_baseline(scene, seconds):
     import oracle_lib as O
     cores = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
     s64 = O.scene_to_f64(scene)
-    probe = 1_000_000
-    t0 = time.perf_counter()
-    t, _ = O.cpu_ref(s64, probe, nthreads=cores)
-    dt = time.perf_counter() - t0
-    rate = int(t["toa_down"].sum()) / dt
-    n = int(max(probe, min(rate * seconds, 5e8)))
-    t0 = time.perf_counter()
-    t, _ = O.cpu_ref(s64, n, nthreads=cores)
-    dt = time.perf_counter() - t0
+    n, dt, t = 2_000_000, 0.0, None
+    for _ in range(4):                      # grow the sample until it runs for >= ~10 s
+        t0 = time.perf_counter()
+        t, _ = O.cpu_ref(s64, n, nthreads=cores)
+        dt = time.perf_counter() - t0
+        if dt >= 0.8 * seconds:
+            break
+        n = int(min(n * max(1.5, 1.1 * seconds / max(dt, 1e-3)), 2e9))
     traced = int(t["toa_down"].sum())
     return {"value": traced / dt, "unit": "photons/s", "cores": cores, "kind": "port",
             "sample": f"{traced} photons of the same scene through oracle/cpu_ref.cpp "

@@ -20,12 +20,13 @@ for d in sorted(glob.glob(f"{src}/pmc_*/")):
     for f in glob.glob(d + "*/*_counter_collection.csv"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "rt_trace_kernel<false, false>" in r["Kernel_Name"] or "rt_trace_kernel" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"]:
+            kn = r["Kernel_Name"]
+            if ("rt_trace_kernel<false, false>" in kn) or ("rt_trace_pool_kernel<false, false" in kn):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 pmc["vgpr"] = int(r["VGPR_Count"]); pmc["sgpr"] = int(r["SGPR_Count"]); pmc["grid"] = int(r["Grid_Size"])
         for k, v in agg.items():
             pmc[k] = sum(v) / len(v)
-stats = [r for r in csv.DictReader(open(f"{here}/{tag}_kernel_stats.csv")) if "rt_trace_kernel" in r["Name"] and "true>" not in r["Name"]]
+stats = [r for r in csv.DictReader(open(f"{here}/{tag}_kernel_stats.csv")) if ("rt_trace_kernel<false, false>" in r["Name"]) or ("rt_trace_pool_kernel<false, false" in r["Name"])]
 pmc["kernel_avg_ns"] = float(stats[0]["AverageNs"]); pmc["kernel_calls"] = int(stats[0]["Calls"])
 pmc["photons_per_launch"] = photons
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:

@@ -55,9 +55,8 @@ constexpr int kBlock = 256;
 // Kernel arguments of the tracer (by value: they live in SGPRs).
 struct TraceArgs
 {
-    const float* k_tot;       // gas + cloud extinction per cell [k][j][i]
-    const float* ssa;         // single-scattering albedo per cell
-    const float2* scat;       // {asy, k_cloud} per cell
+    const float4* cells;      // {k_tot = gas + cloud, ssa, asy, k_cloud} per cell [k][j][i]: one 16-byte
+                              // record, so a collision costs one memory sector however it ends
     const float2* maj;        // {M, 1/M}: ncoarse supervoxels [ck][cj][ci], then one entry per slab
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
@@ -127,7 +126,8 @@ rt_trace_kernel(const TraceArgs a)
     int state = ST_LAUNCH;
     // collision data handed from stage E to stage S
     uint32_t cell = 0;
-    float sc_lhs = 0.f, sc_s = 0.f, sc_umu = 0.f, sc_uphi = 0.f;
+    float sc_asy = 0.f, sc_umu = 0.f, sc_uphi = 0.f;
+    bool sc_cloud = false;
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
@@ -162,10 +162,7 @@ rt_trace_kernel(const TraceArgs a)
                 if (state == ST_SCATTER)
                 {
                     // phase function + rotation, raytracer_kernels.cu:520-548
-                    const float2 ak = a.scat[cell];                 // {asy, k_cloud}
-                    const bool from_cloud = sc_lhs < sc_s * ak.y;   // r/s < k_cloud/k_tot
-                    if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                    const float mu = from_cloud ? henyey_mu(ak.x, sc_umu) : rayleigh_mu(sc_umu);
+                    const float mu = sc_cloud ? henyey_mu(sc_asy, sc_umu) : rayleigh_mu(sc_umu);
                     // |mu| can come out a few ulp above 1 in float: clamp the radicand (the reference
                     // would produce a NaN direction here, raytracer_kernels.cu:523)
                     const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
@@ -211,7 +208,7 @@ rt_trace_kernel(const TraceArgs a)
         {
             if (state == ST_LAUNCH || state == ST_COLLIDE || state == ST_SURFACE)
             {
-                float kt = 0.0f;
+                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (state == ST_LAUNCH)
                 {
                     pid_lo = (uint32_t)next_pid;
@@ -225,8 +222,9 @@ rt_trace_kernel(const TraceArgs a)
                     const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
                     const int k = cell_of(z, a.inv_dz, a.ktot);
                     cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
-                    kt = a.k_tot[cell];
+                    cr = a.cells[cell];
                 }
+                const float kt = cr.x;
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
                 ++nev;
                 // the optical depth to the next collision: third word at launch, second otherwise
@@ -265,10 +263,13 @@ rt_trace_kernel(const TraceArgs a)
                     if (r < p_real)
                     {
                         if (STATS) ++ev_real;
-                        const float s_scat = a.ssa[cell] * p_real;
+                        const float s_scat = cr.y * p_real;
                         if (r <= s_scat)
                         {
-                            sc_lhs = r * kt; sc_s = s_scat; sc_umu = u01(w.z); sc_uphi = u01(w.w);
+                            // gas or cloud: r/s < k_cloud/k_tot (raytracer_kernels.cu:520)
+                            sc_cloud = r * kt < s_scat * cr.w;
+                            sc_asy = cr.z; sc_umu = u01(w.z); sc_uphi = u01(w.w);
+                            if (STATS) { ++ev_scat; if (sc_cloud) ++ev_cscat; }
                             state = ST_SCATTER;
                         }
                         else
@@ -577,7 +578,8 @@ rt_trace_pool_kernel(const TraceArgs a)
             if (active && !(state == PS_LAUNCH && my_pid >= wave_end))
             {
                 uint32_t pid_lo, pid_hi, nev, cell = 0, cks = 0;
-                float kt = 0.0f, inv_m = 0.0f;
+                float inv_m = 0.0f;
+                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (state == PS_LAUNCH)
                 {
                     pid_lo = (uint32_t)my_pid; pid_hi = (uint32_t)(my_pid >> 32); nev = 0;
@@ -596,11 +598,12 @@ rt_trace_pool_kernel(const TraceArgs a)
                         const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
                         const int k = cell_of(g0.z, a.inv_dz, a.ktot);
                         cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
-                        kt = a.k_tot[cell];
+                        cr = a.cells[cell];
                     }
                     else
                         cell = w11;          // surface column stored by the traverse stage
                 }
+                const float kt = cr.x;
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
                 ++nev;
                 float tau_new = free_path_tau(u01(state == PS_LAUNCH ? w.z : w.y));
@@ -638,13 +641,12 @@ rt_trace_pool_kernel(const TraceArgs a)
                     if (rr < p_real)
                     {
                         if (STATS) ++ev_real;
-                        const float s_scat = a.ssa[cell] * p_real;
+                        const float s_scat = cr.y * p_real;
                         if (rr <= s_scat)
                         {
-                            const float2 ak = a.scat[cell];                    // {asy, k_cloud}
-                            const bool from_cloud = rr * kt < s_scat * ak.y;   // r/s < k_cloud/k_tot
+                            const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
                             if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            r4[2] = make_float4(ak.x, u01(w.z), u01(w.w), 0.0f);
+                            r4[2] = make_float4(cr.z, u01(w.z), u01(w.w), 0.0f);
                             r[13] = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
                             ns = PS_SCATTER;
                         }
@@ -833,7 +835,7 @@ rt_trace_pool_kernel(const TraceArgs a)
 // Majorant grid of the cloud slab: one wave per supervoxel, max of k_tot over its cells, stored
 // as {M, 1/M}. (Generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels.)
 __global__ void __launch_bounds__(64)
-rt_majorant_kernel(const float* __restrict__ k_tot, float2* __restrict__ maj,
+rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj,
                    int itot, int jtot, uint32_t ncol, int k_lo, int k_end,
                    int sx, int sy, int sz, int nci, int ncj)
 {
@@ -846,7 +848,7 @@ rt_majorant_kernel(const float* __restrict__ k_tot, float2* __restrict__ maj,
     for (int t = threadIdx.x; t < n; t += 64)
     {
         const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
-        const float v = k_tot[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol];
+        const float v = cells[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol].x;
         m = v > m ? v : m;
     }
 #pragma unroll
@@ -867,7 +869,7 @@ rt_majorant_kernel(const float* __restrict__ k_tot, float2* __restrict__ maj,
 __global__ void __launch_bounds__(kBlock)
 rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_cloud,
                const float* __restrict__ asy,
-               float* __restrict__ k_tot, float2* __restrict__ scat,
+               const float* __restrict__ ssa, float4* __restrict__ cells,
                unsigned int* __restrict__ lev_max_bits, unsigned int* __restrict__ lev_cloud,
                uint32_t ncol, int chunks_per_level)
 {
@@ -880,8 +882,7 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
     {
         const float g = k_gas[base + c], cl = k_cloud[base + c], as = asy[base + c];
         const float kt = g + cl;
-        k_tot[base + c] = kt;
-        scat[base + c] = make_float2(as, cl);
+        cells[base + c] = make_float4(kt, ssa[base + c], as, cl);
         m = kt > m ? kt : m;
         cloudy |= as > 0.0f ? 1u : 0u;
     }
@@ -945,9 +946,7 @@ struct rt_context
     size_t ncol = 0, ncell = 0, nwords = 0;
     int cu_count = 256;
 
-    float* d_k_tot = nullptr;
-    float* d_ssa = nullptr;
-    float2* d_scat = nullptr;
+    float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
@@ -1036,7 +1035,7 @@ int build_majorants(rt_context* c)
     if (ncoarse)
     {
         hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)ncoarse), dim3(64), 0, c->stream,
-                           c->d_k_tot, c->d_maj, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
+                           c->d_cells, c->d_maj, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
                            c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
         RT_HIP(hipGetLastError());
     }
@@ -1057,11 +1056,9 @@ int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, co
     int chunks = (int)((c->ncol + kBlock * 8 - 1) / (kBlock * 8));
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(rt_pack_kernel, dim3(c->ktot * chunks), dim3(kBlock), 0, c->stream,
-                       d_gas, d_cloud, d_asy, c->d_k_tot, c->d_scat, d_lev, d_lev + c->ktot,
+                       d_gas, d_cloud, d_asy, d_ssa, c->d_cells, d_lev, d_lev + c->ktot,
                        (uint32_t)c->ncol, chunks);
     RT_HIP(hipGetLastError());
-    if (d_ssa != c->d_ssa)
-        RT_HIP(hipMemcpyAsync(c->d_ssa, d_ssa, sizeof(float) * c->ncell, hipMemcpyDeviceToDevice, c->stream));
     std::vector<unsigned int> lev(2 * c->ktot);
     RT_HIP(hipMemcpyAsync(lev.data(), d_lev, sizeof(unsigned int) * 2 * c->ktot, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
@@ -1116,9 +1113,7 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
         c->cu_count = prop.multiProcessorCount;
 
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = hipMalloc(&c->d_k_tot, sizeof(float) * ncell);
-    if (e == hipSuccess) e = hipMalloc(&c->d_ssa, sizeof(float) * ncell);
-    if (e == hipSuccess) e = hipMalloc(&c->d_scat, sizeof(float2) * ncell);
+    if (e == hipSuccess) e = hipMalloc(&c->d_cells, sizeof(float4) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
     if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * (RT_N_EVENTS + RT_N_SCHED));
     if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
@@ -1141,9 +1136,7 @@ int rt_destroy(rt_context* c)
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
-    if (c->d_k_tot) (void)hipFree(c->d_k_tot);
-    if (c->d_ssa) (void)hipFree(c->d_ssa);
-    if (c->d_scat) (void)hipFree(c->d_scat);
+    if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_maj) (void)hipFree(c->d_maj);
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
@@ -1158,15 +1151,15 @@ int rt_upload_optics(rt_context* c, const float* k_gas, const float* k_cloud, co
     if (!c || !k_gas || !k_cloud || !ssa || !asy) return fail(RT_ERR_ARG, "rt_upload_optics: null pointer");
     RT_HIP(hipSetDevice(c->device));
     const size_t bytes = sizeof(float) * c->ncell;
-    float* tmp = nullptr;   // gas | cloud | asy staging; ssa goes straight to its final array
-    RT_HIP(hipMalloc(&tmp, 3 * bytes));
+    float* tmp = nullptr;   // gas | cloud | asy | ssa staging for the pack kernel
+    RT_HIP(hipMalloc(&tmp, 4 * bytes));
     hipError_t e = hipMemcpyAsync(tmp, k_gas, bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(tmp + c->ncell, k_cloud, bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * c->ncell, asy, bytes, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->d_ssa, ssa, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + 3 * c->ncell, ssa, bytes, hipMemcpyHostToDevice, c->stream);
     int rc = RT_OK;
     if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_upload_optics: copy failed: %s", hipGetErrorString(e));
-    else rc = pack_from_device(c, tmp, tmp + c->ncell, c->d_ssa, tmp + 2 * c->ncell);
+    else rc = pack_from_device(c, tmp, tmp + c->ncell, tmp + 3 * c->ncell, tmp + 2 * c->ncell);
     (void)hipFree(tmp);
     return rc;
 }
@@ -1252,7 +1245,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     }
 
     TraceArgs a;
-    a.k_tot = c->d_k_tot; a.ssa = c->d_ssa; a.scat = c->d_scat;
+    a.cells = c->d_cells;
     a.tallies = c->d_tallies; a.events = c->d_events;
     a.seed = seed; a.pid_begin = pid_begin; a.pid_end = pid_begin + count;
     a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot;
