@@ -438,7 +438,7 @@ rt_trace_kernel(const TraceArgs a)
 // resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
 // One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
 //
-// LDS per wave: NS records of 16 dwords (AoS, moved as 16-byte groups), NS state words and a
+// LDS per wave: NS records of four 16-byte groups (stored group-major), NS state words and a
 // 64-entry selection list:
 //   g0 {x, y, z, tau}
 //   g1 {ux, uy, uz, nstep}
@@ -507,8 +507,12 @@ rt_trace_pool_kernel(const TraceArgs a)
         const int n = found < 64 ? found : 64;
         const bool active = lane < n;
         const uint32_t slot = active ? sel[lane] : 0u;
-        uint32_t* const r = rec + slot * kPoolRec;
-        float4* const r4 = reinterpret_cast<float4*>(r);
+        // group-major layout: group g of slot s at 16-byte element g*NS + s, so lanes serving
+        // ascending slots read ascending addresses (a slot-major record stride of 64 B would put
+        // every lane on the same four banks)
+        float4* const r4base = reinterpret_cast<float4*>(rec) + slot;
+#define R4(g) r4base[(g) * NS]
+#define RW(k) rec[(((k) >> 2) * NS + slot) * 4 + ((k) & 3)]
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
 
         if (cls == 2u)
@@ -517,9 +521,9 @@ rt_trace_pool_kernel(const TraceArgs a)
             if (active)
             {
                 const uint32_t state = st[slot];
-                const float4 g1 = r4[1];
-                const float4 g2 = r4[2];                     // {asy, u_mu, u_phi, -}
-                const uint32_t cks = r[13];
+                const float4 g1 = R4(1);
+                const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, -}
+                const uint32_t cks = RW(13);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
                 float sp, cp;
                 rt_sincos2pi(g2.z, sp, cp);
@@ -561,9 +565,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                     uy = mu * cp;
                     uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
-                r4[1] = make_float4(ux, uy, uz, g1.w);
-                r4[2] = make_float4(1.0f / ux, 1.0f / uy, 1.0f / uz, 0.0f);
-                r[13] = (cks | (1u << 24)) & ~(1u << 25);      // diffuse from now on
+                R4(1) = make_float4(ux, uy, uz, g1.w);
+                R4(2) = make_float4(1.0f / ux, 1.0f / uy, 1.0f / uz, 0.0f);
+                RW(13) = (cks | (1u << 24)) & ~(1u << 25);      // diffuse from now on
                 ns = PS_TRAVERSE;
             }
         }
@@ -586,14 +590,14 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
                 else
                 {
-                    pid_lo = r[14];
-                    const uint32_t pn = r[15];
+                    pid_lo = RW(14);
+                    const uint32_t pn = RW(15);
                     pid_hi = pn & 0xffu; nev = pn >> 8;
-                    cks = r[13];
-                    const uint32_t w11 = r[11];
+                    cks = RW(13);
+                    const uint32_t w11 = RW(11);
                     if (state == PS_COLLIDE)
                     {
-                        const float4 g0 = r4[0];
+                        const float4 g0 = R4(0);
                         inv_m = __uint_as_float(w11);
                         const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
                         const int k = cell_of(g0.z, a.inv_dz, a.ktot);
@@ -619,12 +623,12 @@ rt_trace_pool_kernel(const TraceArgs a)
                     {
                         ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
                     }
-                    r4[0] = make_float4(x, y, ztop, tau_new);
-                    r4[1] = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
-                    r4[2] = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
-                    r[12] = (uint32_t)ci | ((uint32_t)cj << 16);
-                    r[13] = (uint32_t)ck | ((uint32_t)slab << 16);
-                    r[14] = pid_lo; r[15] = pid_hi | (nev << 8);
+                    R4(0) = make_float4(x, y, ztop, tau_new);
+                    R4(1) = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
+                    R4(2) = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
+                    RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
+                    RW(13) = (uint32_t)ck | ((uint32_t)slab << 16);
+                    RW(14) = pid_lo; RW(15) = pid_hi | (nev << 8);
                     const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
                     tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
                     ns = PS_TRAVERSE;
@@ -636,8 +640,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const float rr = u01(w.x);
                     const float p_real = kt * inv_m;
                     ns = PS_TRAVERSE;
-                    r[3] = __float_as_uint(tau_new);
-                    r[15] = pid_hi | (nev << 8);
+                    RW(3) = __float_as_uint(tau_new);
+                    RW(15) = pid_hi | (nev << 8);
                     if (rr < p_real)
                     {
                         if (STATS) ++ev_real;
@@ -646,8 +650,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                         {
                             const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
                             if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            r4[2] = make_float4(cr.z, u01(w.z), u01(w.w), 0.0f);
-                            r[13] = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
+                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w), 0.0f);
+                            RW(13) = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
                             ns = PS_SCATTER;
                         }
                         else
@@ -663,11 +667,11 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                 {
                     // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    r[15] = pid_hi | (nev << 8);
+                    RW(15) = pid_hi | (nev << 8);
                     if (u01(w.x) <= a.albedo)
                     {
                         tally_add(&a.tallies[4u * a.ncol + cell]);
-                        r[9] = __float_as_uint(u01(w.y)); r[10] = __float_as_uint(u01(w.z));
+                        RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
                         ns = PS_REFLECT;
                     }
                     else
@@ -680,10 +684,10 @@ rt_trace_pool_kernel(const TraceArgs a)
             if (STATS) { ++rounds_t; lanes_t += n; }
             if (active)
             {
-                const float4 g0 = r4[0];
-                const float4 g1 = r4[1];
-                const float4 g2 = r4[2];
-                const uint32_t cicj = r[12], cks = r[13];
+                const float4 g0 = R4(0);
+                const float4 g1 = R4(1);
+                const float4 g2 = R4(2);
+                const uint32_t cicj = RW(12), cks = RW(13);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
                 const float ux = g1.x, uy = g1.y, uz = g1.z;
                 uint32_t nstep = __float_as_uint(g1.w);
@@ -794,15 +798,17 @@ rt_trace_pool_kernel(const TraceArgs a)
                             }
                         }
                     }
-                    r4[0] = make_float4(x, y, z, tau);
-                    r[7] = nstep;
-                    r[11] = w11;
-                    r[12] = (uint32_t)ci | ((uint32_t)cj << 16);
-                    r[13] = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
+                    R4(0) = make_float4(x, y, z, tau);
+                    RW(7) = nstep;
+                    RW(11) = w11;
+                    RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
+                    RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
                 }
             }
         }
 
+#undef R4
+#undef RW
         // ---- publish the new states and update the stage counts ----
         if (active)
             st[slot] = ns;
