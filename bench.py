@@ -34,7 +34,7 @@ WORKLOADS = {
     "c1": ("block_cloud", 26, "C1 block cloud 128x128x128 (raytracer_3d.cu built-in scene)"),
     "c2": ("rayleigh_column", 24, "C2 clear-sky Rayleigh column 64x64x64"),
     "c3": ("cumulus_c3", 26, "C3 broken cumulus 256x256x128, HG cloud + Lambertian surface"),
-    "c4": ("cumulus_c4", 27, "C4 LES cumulus 1024x1024x128 (2^30 photons over 8 GPUs)"),
+    "c4": ("cumulus_c4", 28, "C4 LES cumulus 1024x1024x128 (2^31 photons per step over 8 GPUs)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GLANEOPS = 78643.2   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane per clock
@@ -118,8 +118,7 @@ def main():
         tr.trace(args.seed, begin, n_per_gpu)
         if timed_slot is not None:
             stops[timed_slot].record(stream)
-        if world > 1:
-            dist.all_reduce(tally, op=dist.ReduceOp.SUM)
+        rt.distributed.allreduce_tallies(tally)      # no-op at world size 1
 
     def fence():
         torch.cuda.synchronize()
@@ -176,10 +175,11 @@ def main():
                        "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rt_trace_kernel", "kernel_ms": avg_kernel_ms,
+                         "kernel": "rt_trace_pool_kernel", "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_photon": alg_bytes / n_per_gpu,
                          "events_per_photon": {k: v / n_per_gpu for k, v in ev.items()}},
             "kernel_photons_per_s_per_gpu": n_per_gpu / (avg_kernel_ms * 1e-3),
+            "scheduler": tr.sched_stats(),
         }
         prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(prof):

@@ -2,6 +2,7 @@
 from .tracer import (PhotonTracer, RtError, TALLY_NAMES, EVENT_NAMES, load_library, save_tallies,
                      photon_balance, algorithmic_bytes, split_tally_words)
 from . import scenes
+from . import distributed
 
 __all__ = ["PhotonTracer", "RtError", "TALLY_NAMES", "EVENT_NAMES", "load_library", "save_tallies",
-           "photon_balance", "algorithmic_bytes", "split_tally_words", "scenes"]
+           "photon_balance", "algorithmic_bytes", "split_tally_words", "scenes", "distributed"]

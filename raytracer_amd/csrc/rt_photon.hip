@@ -4,16 +4,17 @@
 // staging code around its launch (raytracer_3d.cu:81-180, raytracer_3d_io.cu:60-77).
 //
 // Design:
-//  * one photon per lane, the whole photon state in VGPRs (the reference keeps it in global
-//    memory, raytracer_kernels.cu:360-473), a persistent grid sized to the chip, lanes pull the
-//    next photon ID the moment their photon ends (regeneration, raytracer_kernels.cu:477-498);
-//  * Philox4x32-10 keyed on (seed, photon id, step, purpose): tallies are integers, so the sum
+//  * photon state never touches HBM (the reference keeps it in global memory,
+//    raytracer_kernels.cu:360-473): the default kernel holds 128 photons per wave in LDS and
+//    compacts those waiting for the same stage (traverse / event / new direction) into full
+//    waves; lanes pull the next photon ID the moment a photon ends (regeneration, :477-498);
+//  * Philox4x32-10 keyed on (seed, photon id, event index): tallies are integers, so the sum
 //    is independent of the launch shape, of the split over calls and of the GPU count;
-//  * optical properties as structure-of-arrays: k_tot (read at every collision test), ssa (only
-//    at real collisions), {asy, k_cloud} (only at scatterings);
+//  * optical properties as one 16-byte record per cell {k_tot, ssa, asy, k_cloud}: a collision
+//    costs one memory sector however it ends;
 //  * null-collision tracking with one majorant per horizontal slab (below / in / above the cloud
-//    layer, the reference's scheme, raytracer_kernels.cu:360-415), restated with an explicit slab
-//    index and the parametric distance to the next slab face instead of in-place nudging.
+//    layer, the reference's scheme, :360-415) and a grid of local majorants over the cloud slab,
+//    traversed face to face with the sampled optical depth carried along.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see __graft_entry__.py).
 
