@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU sample")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend; gloo (tallies staged through host memory) only to rehearse "
+                         "the multi-rank flow on a box with one GPU")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -88,11 +93,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    if args.single_device:
+        if args.backend != "gloo":
+            raise SystemExit("--single-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     factory, default_log2, desc = WORKLOADS[args.workload]
     log2n = args.photons_log2 if args.photons_log2 is not None else default_log2
@@ -118,7 +130,12 @@ def main():
         tr.trace(args.seed, begin, n_per_gpu)
         if timed_slot is not None:
             stops[timed_slot].record(stream)
-        rt.distributed.allreduce_tallies(tally)      # no-op at world size 1
+        if args.backend == "gloo" and world > 1:        # rehearsal path: stage through the host
+            host = tally.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            tally.copy_(host)
+        else:
+            rt.distributed.allreduce_tallies(tally)      # ONE RCCL all-reduce; no-op at world size 1
 
     def fence():
         torch.cuda.synchronize()
@@ -135,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     tr.synchronize()    # raises if any photon was abandoned by the step guard
