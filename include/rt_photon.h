@@ -121,6 +121,11 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change)
+ *   "launch_log2k"   -1 (default): launch positions uniform over the domain top; k >= 0: stratified by
+ *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
+ *                    pass over the columns rotated by a per-pass random offset (stands in for the
+ *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
+ *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round
  *   "pool"           photons each wave keeps in LDS (64, 96, 128, 160, 192 or 256) and compacts by
  *                    stage into full waves; 0 = photon state stays in the lane's registers
  *                    (scheduling only: results do not change). "pool_waves_per_cu" caps residency.

@@ -205,6 +205,8 @@ typedef struct
     float zenith_rad, azimuth_rad, albedo;
     int fixed_dot; /* 0 = dot() as the reference writes it (v1.z*v1.z), 1 = v1.z*v2.z */
     int sx, sy, sz; /* supervoxel size in cells for the majorant grid of the cloud slab; 0 = none */
+    int launch_log2k; /* < 0: launch positions uniform over the domain (one Philox draw per axis);
+                         >= 0: stratified by column, 2^launch_log2k consecutive photon IDs per column */
 } oracle_scene_t;
 
 /* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
@@ -358,8 +360,32 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
 
     /* launch, raytracer_kernels.cu:180-208 */
     draw(seed, pid, nev++, 0u, w);
-    float x = xs * u01(w[0]);
-    float y = ys * u01(w[1]);
+    float x, y;
+    if (sc->launch_log2k < 0)
+    {
+        x = xs * u01(w[0]);
+        y = ys * u01(w[1]);
+    }
+    else
+    {
+        /* Stratified launch (stands in for the reference's scrambled-Sobol positions,
+         * raytracer_kernels.cu:239-253, 331: low-discrepancy, here keyed on the photon ID).
+         * Consecutive groups of K = 2^log2k IDs go to consecutive columns in row-major order; one
+         * pass over all columns takes ncol*K IDs and is rotated by a random offset drawn per
+         * pass, so that any prefix of the ID sequence is unbiased; within the column the position
+         * is uniform. */
+        const uint64_t ncol = (uint64_t)itot * jtot;
+        const uint64_t qt = pid >> sc->launch_log2k;
+        const uint64_t pass = qt / ncol, q = qt % ncol;
+        uint32_t wp[4];
+        draw(seed, pass, 0xFFFFFFFFu, 1u, wp);
+        const uint64_t off = ((uint64_t)wp[0] * ncol) >> 32;
+        uint64_t c = q + off;
+        if (c >= ncol) c -= ncol;
+        const uint32_t jc = (uint32_t)(c / (uint64_t)itot), ic = (uint32_t)(c % (uint64_t)itot);
+        x = fmaf(u01(w[0]), sc->dx, (float)ic * sc->dx);
+        y = fmaf(u01(w[1]), sc->dy, (float)jc * sc->dy);
+    }
     float tau = free_path_tau(u01(w[2]));
     if (!(tau > 0.0f)) tau = 0.0f;
     float z = sl->zface[sl->nslab];

@@ -77,6 +77,12 @@ struct TraceArgs
     uint32_t ncoarse;
     float hx, hy, hz, inv_hx, inv_hy, zc0, zc1;
     int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
+    int th_launch;            // pool kernel: waiting launches that trigger a launch round
+    // stratified launch (launch_log2k >= 0): 2^k consecutive photon IDs per column, columns in
+    // row-major order, each pass over the columns rotated by a per-pass random offset
+    int launch_log2k;
+    float dx, dy;
+    uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
 };
 
 __device__ __forceinline__ void tally_add(unsigned long long* p)
@@ -91,6 +97,31 @@ __device__ __forceinline__ float face_distance(float face, float pos, float inv_
 {
     const float t = (face - pos) * inv_u;
     return t >= 0.0f ? t : (t > -__builtin_inff() ? 0.0f : __builtin_inff());
+}
+
+// Rotation of pass p of the stratified launch: a Philox draw keyed on the pass index.
+__device__ __forceinline__ uint32_t launch_pass_offset(uint64_t pass, uint32_t ncol, uint32_t key0, uint32_t key1)
+{
+    const rt::u32x4 w = rt::philox4x32_10((uint32_t)pass, (uint32_t)(pass >> 32), 0xFFFFFFFFu, 1u, key0, key1);
+    return (uint32_t)(((uint64_t)w.x * ncol) >> 32);
+}
+
+// Column (i, j) of rotated column index c: row-major, division by itot through the host's magic number.
+__device__ __forceinline__ void launch_column(const TraceArgs& a, uint32_t c, uint32_t& i, uint32_t& j)
+{
+    j = (uint32_t)(((uint64_t)c * a.div_itot_mul) >> a.div_itot_shift);
+    i = c - j * (uint32_t)a.itot;
+}
+
+// Exact (slow) form of the stratified column of one photon ID: 64-bit division per photon.
+__device__ __forceinline__ uint32_t launch_column_index_exact(const TraceArgs& a, uint64_t pid, uint32_t key0, uint32_t key1)
+{
+    const uint64_t qt = pid >> a.launch_log2k;
+    const uint64_t pass = qt / a.ncol;
+    const uint32_t q = (uint32_t)(qt - pass * a.ncol);
+    uint32_t c = q + launch_pass_offset(pass, a.ncol, key0, key1);      // < 2 * ncol < 2^32
+    if (c >= a.ncol) c -= a.ncol;
+    return c;
 }
 
 enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5, ST_REFLECT = 6 };
@@ -235,8 +266,18 @@ rt_trace_kernel(const TraceArgs a)
                 if (state == ST_LAUNCH)
                 {
                     // launch at the top of the domain, raytracer_kernels.cu:180-208
-                    x = a.xs * u01(w.x);
-                    y = a.ys * u01(w.y);
+                    if (a.launch_log2k < 0)
+                    {
+                        x = a.xs * u01(w.x);
+                        y = a.ys * u01(w.y);
+                    }
+                    else
+                    {
+                        uint32_t ic, jc;
+                        launch_column(a, launch_column_index_exact(a, ((uint64_t)pid_hi << 32) | pid_lo, key0, key1), ic, jc);
+                        x = fma_(u01(w.x), a.dx, (float)ic * a.dx);
+                        y = fma_(u01(w.y), a.dy, (float)jc * a.dy);
+                    }
                     tau = tau_new;
                     z = ztop;
                     ux = a.sun_x; uy = a.sun_y; uz = a.sun_z;
@@ -447,7 +488,7 @@ rt_trace_kernel(const TraceArgs a)
 //                              (traverse -> surface event). While a photon waits for stage S the
 //                              group holds {asy, u_mu, u_phi, -}: the reciprocals are dead then.
 //   g3 {ci | cj << 16, ck | slab << 16 | diffuse << 24 | from_cloud << 25, pid_lo, pid_hi | nev << 8}
-enum : uint32_t { PS_TRAVERSE = 0, PS_LAUNCH = 4, PS_COLLIDE = 5, PS_SURFACE = 6, PS_SCATTER = 8, PS_REFLECT = 9, PS_DONE = 12 };
+enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_DONE = 16 };
 constexpr int kPoolRec = 16;
 constexpr int kPoolBlock = 64;
 
@@ -479,16 +520,33 @@ rt_trace_pool_kernel(const TraceArgs a)
 #pragma unroll
     for (int h = 0; h < kHalves; ++h)
         st[h * 64 + lane] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
-    int n_t = 0, n_e = NS, n_s = 0;      // photons waiting per stage (wave-uniform)
+    int n_t = 0, n_e = 0, n_s = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
+
+    // stratified launch: column-order position of wave_next, kept incrementally (fast path for
+    // grids of >= 128 columns, where one round of <= 64 launches wraps the column index at most once)
+    const bool strat_fast = a.launch_log2k >= 0 && a.ncol >= 128u;
+    uint64_t qt0 = 0, pass_cur = 0;
+    uint32_t q_cur = 0, off_cur = 0, off_next = 0;
+    if (strat_fast)
+    {
+        qt0 = wave_next >> a.launch_log2k;
+        pass_cur = qt0 / a.ncol;
+        q_cur = (uint32_t)(qt0 - pass_cur * a.ncol);
+        off_cur = launch_pass_offset(pass_cur, a.ncol, key0, key1);
+        off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
+    }
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
     uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0;
 
-    while (n_t + n_e + n_s > 0)
+    while (n_t + n_e + n_s + n_l > 0)
     {
-        // serve the stage with the most photons waiting (ties: traverse, then event)
-        const uint32_t cls = (n_t >= n_e && n_t >= n_s) ? 0u : (n_e >= n_s ? 1u : 2u);
+        // serve the stage with the most photons waiting (ties: traverse, then event); launches
+        // (regeneration) once th_launch slots are free or nothing else is left
+        uint32_t cls = (n_t >= n_e && n_t >= n_s) ? 0u : (n_e >= n_s ? 1u : 2u);
+        if (n_l >= a.th_launch || n_t + n_e + n_s == 0)
+            cls = 3u;
 
         // ---- gather up to 64 waiting slots into the lanes ----
         asm volatile("" ::: "memory");
@@ -575,66 +633,36 @@ rt_trace_pool_kernel(const TraceArgs a)
         else if (cls == 1u)
         {
             if (STATS) { ++rounds_e; lanes_e += n; }
-            // photon IDs for the launching lanes of this round
-            const uint32_t state = active ? st[slot] : PS_DONE;
-            const unsigned long long ml = __ballot(state == PS_LAUNCH);
-            const uint64_t my_pid = wave_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u));
-            wave_next += __popcll(ml);
-            if (active && !(state == PS_LAUNCH && my_pid >= wave_end))
+            if (active)
             {
-                uint32_t pid_lo, pid_hi, nev, cell = 0, cks = 0;
+                const uint32_t state = st[slot];
+                uint32_t cell = 0;
                 float inv_m = 0.0f;
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (state == PS_LAUNCH)
+                const uint32_t pid_lo = RW(14);
+                const uint32_t pn = RW(15);
+                const uint32_t pid_hi = pn & 0xffu;
+                uint32_t nev = pn >> 8;
+                const uint32_t cks = RW(13);
+                const uint32_t w11 = RW(11);
+                if (state == PS_COLLIDE)
                 {
-                    pid_lo = (uint32_t)my_pid; pid_hi = (uint32_t)(my_pid >> 32); nev = 0;
+                    const float4 g0 = R4(0);
+                    inv_m = __uint_as_float(w11);
+                    const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
+                    const int k = cell_of(g0.z, a.inv_dz, a.ktot);
+                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
+                    cr = a.cells[cell];
                 }
                 else
-                {
-                    pid_lo = RW(14);
-                    const uint32_t pn = RW(15);
-                    pid_hi = pn & 0xffu; nev = pn >> 8;
-                    cks = RW(13);
-                    const uint32_t w11 = RW(11);
-                    if (state == PS_COLLIDE)
-                    {
-                        const float4 g0 = R4(0);
-                        inv_m = __uint_as_float(w11);
-                        const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
-                        const int k = cell_of(g0.z, a.inv_dz, a.ktot);
-                        cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
-                        cr = a.cells[cell];
-                    }
-                    else
-                        cell = w11;          // surface column stored by the traverse stage
-                }
+                    cell = w11;          // surface column stored by the traverse stage
                 const float kt = cr.x;
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
                 ++nev;
-                float tau_new = free_path_tau(u01(state == PS_LAUNCH ? w.z : w.y));
+                float tau_new = free_path_tau(u01(w.y));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
 
-                if (state == PS_LAUNCH)
-                {
-                    // launch at the top of the domain, raytracer_kernels.cu:180-208
-                    const float x = a.xs * u01(w.x), y = a.ys * u01(w.y);
-                    const int slab = a.nslab - 1;
-                    int ci = 0, cj = 0, ck = 0;
-                    if (slab == a.gslab)
-                    {
-                        ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
-                    }
-                    R4(0) = make_float4(x, y, ztop, tau_new);
-                    R4(1) = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
-                    R4(2) = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
-                    RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
-                    RW(13) = (uint32_t)ck | ((uint32_t)slab << 16);
-                    RW(14) = pid_lo; RW(15) = pid_hi | (nev << 8);
-                    const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                    tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
-                    ns = PS_TRAVERSE;
-                }
-                else if (state == PS_COLLIDE)
+                if (state == PS_COLLIDE)
                 {
                     // collision classification, raytracer_kernels.cu:507-518
                     if (STATS) ++ev_coll;
@@ -677,6 +705,74 @@ rt_trace_pool_kernel(const TraceArgs a)
                     }
                     else
                         ns = PS_LAUNCH;
+                }
+            }
+        }
+        else if (cls == 3u)
+        {
+            // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
+            const uint64_t my_pid = wave_next + (uint64_t)lane;
+            const bool go = active && my_pid < wave_end;
+            if (go)
+            {
+                const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, 0u, key0, key1);
+                float tau_new = free_path_tau(u01(w.z));
+                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
+                float x, y;
+                if (a.launch_log2k < 0)
+                {
+                    x = a.xs * u01(w.x);
+                    y = a.ys * u01(w.y);
+                }
+                else
+                {
+                    uint32_t c;
+                    if (strat_fast)
+                    {
+                        uint32_t q = q_cur + (uint32_t)((my_pid >> a.launch_log2k) - qt0);
+                        uint32_t o = off_cur;
+                        if (q >= a.ncol) { q -= a.ncol; o = off_next; }
+                        c = q + o;
+                        if (c >= a.ncol) c -= a.ncol;
+                    }
+                    else
+                        c = launch_column_index_exact(a, my_pid, key0, key1);
+                    uint32_t ic, jc;
+                    launch_column(a, c, ic, jc);
+                    x = fma_(u01(w.x), a.dx, (float)ic * a.dx);
+                    y = fma_(u01(w.y), a.dy, (float)jc * a.dy);
+                }
+                const int slab = a.nslab - 1;
+                int ci = 0, cj = 0, ck = 0;
+                if (slab == a.gslab)
+                {
+                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
+                }
+                R4(0) = make_float4(x, y, ztop, tau_new);
+                R4(1) = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
+                R4(2) = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
+                R4(3) = make_float4(__uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)),
+                                    __uint_as_float((uint32_t)ck | ((uint32_t)slab << 16)),
+                                    __uint_as_float(pid_lo), __uint_as_float(pid_hi | (1u << 8)));
+                const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
+                tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                ns = PS_TRAVERSE;
+            }
+            // advance the wave's ID cursor (and, stratified, its column cursor) by the lanes served
+            const uint64_t left = wave_end - wave_next;
+            wave_next += (uint64_t)n < left ? (uint64_t)n : left;
+            if (strat_fast)
+            {
+                const uint64_t qt1 = wave_next >> a.launch_log2k;
+                q_cur += (uint32_t)(qt1 - qt0);
+                qt0 = qt1;
+                if (q_cur >= a.ncol)
+                {
+                    q_cur -= a.ncol;
+                    ++pass_cur;
+                    off_cur = off_next;
+                    off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
                 }
             }
         }
@@ -813,10 +909,11 @@ rt_trace_pool_kernel(const TraceArgs a)
         // ---- publish the new states and update the stage counts ----
         if (active)
             st[slot] = ns;
-        const uint32_t ncls = active ? (ns >> 2) : 3u;
-        const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)), d_s = __popcll(__ballot(ncls == 2u));
-        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else n_s -= n;
-        n_t += d_t; n_e += d_e; n_s += d_s;
+        const uint32_t ncls = active ? (ns >> 2) : 4u;
+        const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
+                  d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u));
+        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else if (cls == 2u) n_s -= n; else n_l -= n;
+        n_t += d_t; n_e += d_e; n_s += d_s; n_l += d_l;
     }
 
     if (STATS)
@@ -961,6 +1058,8 @@ struct rt_context
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
+    int th_launch = 32;               // pool kernel: free slots that trigger a launch round
+    int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
@@ -1210,6 +1309,16 @@ int rt_set_option(rt_context* c, const char* name, long long value)
             return fail(RT_ERR_ARG, "rt_set_option: pool %lld not one of 0, 64, 96, 128, 160, 192, 256", value);
         c->pool = (int)value;
     }
+    else if (!strcmp(name, "launch_log2k"))
+    {
+        if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
+        c->launch_log2k = (int)value;
+    }
+    else if (!strcmp(name, "th_launch"))
+    {
+        if (value < 1 || value > 256) return fail(RT_ERR_ARG, "rt_set_option: th_launch %lld outside [1,256]", value);
+        c->th_launch = (int)value;
+    }
     else if (!strcmp(name, "pool_waves_per_cu"))
     {
         if (value < 1 || value > 32) return fail(RT_ERR_ARG, "rt_set_option: pool_waves_per_cu %lld outside [1,32]", value);
@@ -1273,6 +1382,16 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.inv_hx = a.gslab >= 0 ? 1.0f / a.hx : 0.0f; a.inv_hy = a.gslab >= 0 ? 1.0f / a.hy : 0.0f;
     a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
     a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
+    a.th_launch = c->th_launch;
+    a.launch_log2k = c->launch_log2k;
+    a.dx = c->dx; a.dy = c->dy;
+    {
+        // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
+        int l = 0;
+        while ((1u << l) < (uint32_t)c->itot) ++l;
+        a.div_itot_shift = 31u + (uint32_t)l;
+        a.div_itot_mul = (uint32_t)(((1ull << a.div_itot_shift) / (uint64_t)c->itot) + 1ull);
+    }
 
     uint64_t blocks = (count + kBlock - 1) / kBlock;
     const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;

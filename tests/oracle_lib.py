@@ -26,7 +26,8 @@ class OracleScene(C.Structure):
     _fields_ = [("itot", C.c_int), ("jtot", C.c_int), ("ktot", C.c_int),
                 ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
                 ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
-                ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int)]
+                ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int),
+                ("launch_log2k", C.c_int)]
 
 
 class OracleSlabs(C.Structure):
@@ -92,20 +93,20 @@ def new_tallies(scene):
 DEFAULT_SUPERGRID = (8, 8, 4)     # must equal the product's default (rt_set_option "supergrid_*")
 
 
-def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID) -> OracleScene:
+def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1) -> OracleScene:
     f = np.float32
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
-                       scene.albedo, int(fixed_dot), sx, sy, sz)
+                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k))
 
 
 def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False,
-                  supergrid=DEFAULT_SUPERGRID):
+                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1):
     """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
     t = tallies if tallies is not None else new_tallies(scene)
     ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
-    sc = oracle_scene(scene, fixed_dot, supergrid)
+    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k)
     fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
                                    seed, pid_begin, count, nthreads,

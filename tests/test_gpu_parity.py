@@ -310,8 +310,39 @@ def test_c3_cumulus_statistics_against_reference_restatement(rt):
         sig = np.sqrt(max(pb * (1 - pb), 1e-12) * (1 / na + 1 / nb))
         assert abs(pa - pb) < 4 * sig, (name, pa, pb, (pa - pb) / sig)
     for name in ("surface_down_direct", "surface_down_diffuse", "toa_up"):
-        xa, xb = a[name].astype(np.float64).ravel(), b[name].astype(np.float64).ravel()
-        m = (xa / na * nb + xb) >= 40
+        blk = lambda v: v.astype(np.float64).reshape(64, 4, 64, 4).sum(axis=(1, 3)).ravel()   # 4x4 columns
+        xa, xb = blk(a[name]), blk(b[name])
+        m = xb >= 40
         pooled = (xa + xb) / (na + nb)
         z = ((xa / na - xb / nb) / np.sqrt(pooled * (1 / na + 1 / nb)))[m]
         assert z.size > 1000 and np.max(np.abs(z)) < 6.5 and 0.9 < np.mean(z ** 2) < 1.1, (name, np.mean(z ** 2), np.max(np.abs(z)))
+
+
+@pytest.mark.parametrize("pool", [0, 128])
+@pytest.mark.parametrize("scene_name,n,log2k", [("tiny", 192 * 32 * 3 + 777, 5), ("tiny", 50000, 0), ("tiny", 50000, 9),
+                                                ("few_columns", 40000, 3), ("few_columns", 40000, 0),
+                                                ("block_cloud", 1 << 18, 5), ("cumulus_small", 1 << 17, 4)])
+def test_stratified_launch_bit_identical_to_oracle(rt, pool, scene_name, n, log2k):
+    """Stratified launch (2^k consecutive photon IDs per column, rotated passes): both kernels
+    against the oracle, including grids with < 128 columns (exact-division path) and ID ranges
+    that start in the middle of a pass."""
+    scene = rt.scenes.cumulus(8, 6, 10, 100.0, 80.0, 60.0, n_clouds=2, seed=2, z_base=180.0, z_top=480.0) \
+        if scene_name == "few_columns" else SCENES[scene_name](rt.scenes)
+    begin = 123_456_789_012
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, launch_log2k=log2k)
+    tr.trace(99, begin, n); tr.synchronize()
+    want, ev = O.photon_oracle(scene, 99, begin, n, launch_log2k=log2k)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev
+    tr.close()
+
+
+def test_stratified_launch_is_uniform_over_full_passes(rt):
+    scene = rt.scenes.tiny()
+    k = 5
+    tr = rt.PhotonTracer.from_scene(scene, launch_log2k=k)
+    n = scene.ncol * (1 << k) * 4
+    tr.trace(1, 0, n); tr.synchronize()
+    td = tr.tallies()["toa_down"].astype(np.int64)
+    # every column gets 4 * 2^k photons up to float rounding at column edges
+    assert abs(td - 4 * (1 << k)).max() <= 2 and int(td.sum()) == n
