@@ -78,6 +78,7 @@ struct TraceArgs
     float hx, hy, hz, inv_hx, inv_hy, zc0, zc1;
     int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
     int th_launch;            // pool kernel: waiting launches that trigger a launch round
+    int t_iters;              // pool kernel: majorant regions a photon may cross in one traverse round
     // stratified launch (launch_log2k >= 0): 2^k consecutive photon IDs per column, columns in
     // row-major order, each pass over the columns rotated by a per-pass random offset
     int launch_log2k;
@@ -792,6 +793,11 @@ rt_trace_pool_kernel(const TraceArgs a)
                 int slab = (int)((cks >> 16) & 0xffu);
                 const bool diffuse = (cks >> 24) & 1u;
                 ns = PS_TRAVERSE;
+                uint32_t w11 = RW(11);
+                // up to t_iters regions per round: a photon that only crossed a face goes on at once
+                // (saves the slot selection and the LDS round trip of a further round)
+                for (int it = 0; it < a.t_iters && ns == PS_TRAVERSE; ++it)
+                {
                 if (nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
                 {
                     tally_add(&a.events[RT_EV_ABORT]);
@@ -831,7 +837,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const float tt = hit ? t_exit : dn;
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
                     if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
-                    uint32_t w11 = __float_as_uint(mm.y);
+                    w11 = __float_as_uint(mm.y);
 
                     if (!hit)
                         ns = PS_COLLIDE;
@@ -895,12 +901,13 @@ rt_trace_pool_kernel(const TraceArgs a)
                             }
                         }
                     }
-                    R4(0) = make_float4(x, y, z, tau);
-                    RW(7) = nstep;
-                    RW(11) = w11;
-                    RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
-                    RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
                 }
+                }
+                R4(0) = make_float4(x, y, z, tau);
+                RW(7) = nstep;
+                RW(11) = w11;
+                RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
             }
         }
 
@@ -1059,6 +1066,7 @@ struct rt_context
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
     int th_launch = 32;               // pool kernel: free slots that trigger a launch round
+    int t_iters = 1;                  // pool kernel: regions crossed per traverse round (more was not faster)
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
@@ -1314,6 +1322,11 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
         c->launch_log2k = (int)value;
     }
+    else if (!strcmp(name, "t_iters"))
+    {
+        if (value < 1 || value > 64) return fail(RT_ERR_ARG, "rt_set_option: t_iters %lld outside [1,64]", value);
+        c->t_iters = (int)value;
+    }
     else if (!strcmp(name, "th_launch"))
     {
         if (value < 1 || value > 256) return fail(RT_ERR_ARG, "rt_set_option: th_launch %lld outside [1,256]", value);
@@ -1383,6 +1396,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
     a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
     a.th_launch = c->th_launch;
+    a.t_iters = c->t_iters;
     a.launch_log2k = c->launch_log2k;
     a.dx = c->dx; a.dy = c->dy;
     {
