@@ -127,6 +127,8 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
  *   "t_iters"        majorant regions a photon may cross within one traverse round of the pool kernel
  *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round
+ *   "chunk"          photon IDs a wave of the pool kernel takes at a time from the device-wide cursor
+ *                    (power of two, default 256; halved for small jobs until every wave finds work)
  *   "pool"           photons each wave keeps in LDS (64, 96, 128, 160, 192 or 256) and compacts by
  *                    stage into full waves; 0 = photon state stays in the lane's registers
  *                    (scheduling only: results do not change). "pool_waves_per_cu" caps residency.

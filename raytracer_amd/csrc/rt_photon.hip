@@ -51,6 +51,10 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 constexpr int kBlock = 256;
+// device words behind rt_context::d_events: RT_N_EVENTS counters, RT_N_SCHED scheduler statistics,
+// and (on a cache line of its own) the photon-ID cursor of the pool kernel
+constexpr int kCursorWord = 32;
+constexpr int kEventWords = 48;
 
 // ------------------------------------------------------------------------------------------
 // Kernel arguments of the tracer (by value: they live in SGPRs).
@@ -84,6 +88,10 @@ struct TraceArgs
     int launch_log2k;
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
+    // pool kernel: photon IDs are handed out in chunks of `chunk` from a device-wide cursor, so
+    // the launch needs no static partition (waves that start late or run slower simply take fewer)
+    unsigned long long* cursor;
+    uint32_t chunk;
 };
 
 __device__ __forceinline__ void tally_add(unsigned long long* p)
@@ -507,13 +515,10 @@ rt_trace_pool_kernel(const TraceArgs a)
     uint32_t* const st = rec + NS * kPoolRec;                   // state words (padded to kHalves*64)
     uint32_t* const sel = st + kHalves * 64;                    // 64 selected slots
 
-    // contiguous photon-ID range of this wave
-    const uint64_t nwaves = gridDim.x;
-    const uint64_t wave_id = blockIdx.x;
+    // photon IDs of this wave: chunks [wave_next, wave_end) taken from the device-wide cursor
     const uint64_t total = a.pid_end - a.pid_begin;
-    const uint64_t per_wave = (total + nwaves - 1) / nwaves;
-    uint64_t wave_next = a.pid_begin + (wave_id * per_wave < total ? wave_id * per_wave : total);
-    const uint64_t wave_end = a.pid_begin + ((wave_id + 1) * per_wave < total ? (wave_id + 1) * per_wave : total);
+    uint64_t wave_next = 0, wave_end = 0;
+    bool exhausted = false;
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
     const float ztop = a.zface[a.nslab];
@@ -528,14 +533,6 @@ rt_trace_pool_kernel(const TraceArgs a)
     const bool strat_fast = a.launch_log2k >= 0 && a.ncol >= 128u;
     uint64_t qt0 = 0, pass_cur = 0;
     uint32_t q_cur = 0, off_cur = 0, off_next = 0;
-    if (strat_fast)
-    {
-        qt0 = wave_next >> a.launch_log2k;
-        pass_cur = qt0 / a.ncol;
-        q_cur = (uint32_t)(qt0 - pass_cur * a.ncol);
-        off_cur = launch_pass_offset(pass_cur, a.ncol, key0, key1);
-        off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
-    }
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
@@ -712,8 +709,36 @@ rt_trace_pool_kernel(const TraceArgs a)
         else if (cls == 3u)
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
+            if (wave_next == wave_end && !exhausted)
+            {
+                // next chunk of IDs: one returning atomic per chunk, broadcast from lane 0
+                unsigned long long c0 = 0;
+                if (lane == 0)
+                    c0 = __hip_atomic_fetch_add(a.cursor, (unsigned long long)a.chunk, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t c0_lo = __builtin_amdgcn_readfirstlane((uint32_t)c0);
+                const uint32_t c0_hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
+                c0 = ((unsigned long long)c0_hi << 32) | c0_lo;
+                if (c0 >= total)
+                    exhausted = true;
+                else
+                {
+                    wave_next = a.pid_begin + c0;
+                    wave_end = a.pid_begin + (c0 + a.chunk < total ? c0 + a.chunk : total);
+                    if (strat_fast)
+                    {
+                        qt0 = wave_next >> a.launch_log2k;
+                        pass_cur = qt0 / a.ncol;
+                        q_cur = (uint32_t)(qt0 - pass_cur * a.ncol);
+                        off_cur = launch_pass_offset(pass_cur, a.ncol, key0, key1);
+                        off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
+                    }
+                }
+            }
             const uint64_t my_pid = wave_next + (uint64_t)lane;
             const bool go = active && my_pid < wave_end;
+            if (active && !exhausted)
+                ns = PS_LAUNCH;          // no ID left in this chunk: wait for the next one
             if (go)
             {
                 const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
@@ -1066,6 +1091,7 @@ struct rt_context
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
     int th_launch = 32;               // pool kernel: free slots that trigger a launch round
+    int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int t_iters = 1;                  // pool kernel: regions crossed per traverse round (more was not faster)
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     unsigned long long* d_tallies = nullptr;
@@ -1229,9 +1255,9 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc(&c->d_cells, sizeof(float4) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
-    if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * (RT_N_EVENTS + RT_N_SCHED));
+    if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * kEventWords);
     if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
-    if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * (RT_N_EVENTS + RT_N_SCHED));
+    if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * kEventWords);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e != hipSuccess)
@@ -1327,6 +1353,12 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value < 1 || value > 64) return fail(RT_ERR_ARG, "rt_set_option: t_iters %lld outside [1,64]", value);
         c->t_iters = (int)value;
     }
+    else if (!strcmp(name, "chunk"))
+    {
+        if (value < 64 || value > (1 << 20) || (value & (value - 1)))
+            return fail(RT_ERR_ARG, "rt_set_option: chunk %lld not a power of two in [64, 2^20]", value);
+        c->chunk = (int)value;
+    }
     else if (!strcmp(name, "th_launch"))
     {
         if (value < 1 || value > 256) return fail(RT_ERR_ARG, "rt_set_option: th_launch %lld outside [1,256]", value);
@@ -1411,6 +1443,8 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
     if (blocks > cap) blocks = cap;
 
+    if (c->pool > 0)
+        RT_HIP(hipMemsetAsync(c->d_events + kCursorWord, 0, sizeof(unsigned long long), c->stream));
     RT_HIP(hipEventRecord(c->ev_start, c->stream));
     const dim3 block(kBlock);
     if (c->pool > 0)
@@ -1423,8 +1457,14 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         int per_cu = (int)((160u * 1024u) / lds_bytes);
         if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
         if (per_cu < 1) per_cu = 1;
-        uint64_t pblocks = (count + (uint64_t)ns - 1) / (uint64_t)ns;
         const uint64_t pcap = (uint64_t)c->cu_count * per_cu;
+        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
+        // every resident wave still finds work
+        uint32_t chunk = (uint32_t)c->chunk;
+        while (chunk > 64u && count / chunk < 4u * pcap) chunk >>= 1;
+        a.cursor = c->d_events + kCursorWord;
+        a.chunk = chunk;
+        uint64_t pblocks = (count + chunk - 1) / chunk;
         if (pblocks > pcap) pblocks = pcap;
         const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
 #define RT_LAUNCH_POOL(NS)                                                                                         \

@@ -164,6 +164,21 @@ def test_pool_kernel_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid)
     tr.close()
 
 
+@pytest.mark.parametrize("chunk,n", [(64, 1 << 16), (512, 1 << 16), (4096, 1 << 17), (1 << 16, 100_003), (512, 777)])
+def test_chunked_id_distribution_does_not_change_results(rt, chunk, n):
+    """The pool kernel hands photon IDs to its waves in chunks from a device-wide cursor: which wave
+    traces which photon varies from run to run, the tallies and event counts must not."""
+    scene = rt.scenes.tiny()
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, chunk=chunk)
+    want, ev = O.photon_oracle(scene, 31, 5_000_000_123, n)
+    for _ in range(2):
+        tr.reset()
+        tr.trace(31, 5_000_000_123, n); tr.synchronize()
+        _assert_same(tr.tallies(), want)
+        assert tr.events() == ev
+    tr.close()
+
+
 def test_frozen_golden_vector(rt):
     import os
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "photon_oracle_tiny.npz"))

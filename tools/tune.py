@@ -20,7 +20,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=0, t_iters=1, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=0, chunk=512, t_iters=1, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
 run(base, 1)
 res = []
 if what == "thresholds":
@@ -32,6 +32,12 @@ elif what == "grid":
 elif what == "pool":
     for pl, b in ((0, 32), (64, 32), (64, 24), (96, 32), (96, 20), (96, 16), (128, 32), (128, 16), (128, 12), (160, 32), (160, 12), (192, 32), (256, 32)):
         o = dict(base, pool=pl, pool_waves_per_cu=b); res.append((run(o), pl, b))
+elif what == "pool2":
+    for pl, b in ((64, 32), (64, 24), (96, 23), (96, 20), (96, 16), (128, 32), (128, 18), (128, 16), (128, 14), (128, 12), (160, 14), (160, 12), (192, 12), (192, 10), (256, 8)):
+        o = dict(base, pool=pl, pool_waves_per_cu=b); res.append((run(o), pl, b))
+elif what == "chunk":
+    for ch in (64, 128, 256, 512, 1024, 2048, 4096, 16384):
+        o = dict(base, pool=128, chunk=ch); res.append((run(o, 5), ch))
 elif what == "launch":
     for lk, thl in ((-1, 32), (-1, 16), (-1, 48), (-1, 64), (-1, 96), (5, 32), (3, 32), (7, 32), (0, 32), (10, 32), (5, 64)):
         o = dict(base, pool=128, launch_log2k=lk, th_launch=thl); res.append((run(o, 5), lk, thl))
@@ -42,6 +48,6 @@ elif what == "blocks":
     for b in (2, 3, 4, 5, 6, 7, 8, 10, 12):
         o = dict(base, blocks_per_cu=b); res.append((run(o), b))
 res.sort()
-for r in res[:12]:
+for r in res[:16]:
     print(wl, what, "ms=%.3f" % r[0], "Gph/s=%.3f" % (n / r[0] / 1e6), r[1:])
 print("worst", res[-1])
