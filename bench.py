@@ -9,7 +9,9 @@ A "step" is one complete job on the workload's grid: zero the tallies, trace thi
 photons (IDs keyed by step and rank, so every photon of the run is distinct), and — for N > 1 —
 sum the tallies over ranks with ONE all-reduce (RCCL over xGMI; the path's only exchange step,
 SURVEY.md §8e). Work per GPU is fixed as N grows (weak scaling). Inputs are resident in HBM before
-the timed region (grids uploaded and packed once).
+the timed region (grids uploaded and packed once). For N > 1 the tallies are double-buffered and the
+all-reduce of step k runs on RCCL's stream beside the trace of step k+1 (the way a zenith sweep
+pipelines its jobs); all of it lies inside the timed region, which ends with every stream idle.
 
 Prints ONE JSON line on rank 0 (metric of BASELINE.json: photons/sec, whole node) carrying
   roofline      algorithmic bytes per launch (from the kernel's own event counters, SURVEY.md
@@ -56,6 +58,10 @@ def parse():
                          "the multi-rank flow on a box with one GPU")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for each step's all-reduce before the next step starts")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the collective code path even at world size 1")
     return ap.parse_args()
 
 
@@ -99,8 +105,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
@@ -116,13 +127,24 @@ def main():
         tr.set_option("blocks_per_cu", args.blocks_per_cu)
     stream = torch.cuda.current_stream()
     tr.set_stream(stream.cuda_stream)
-    tally = torch.zeros(tr.nwords, dtype=torch.int64, device=dev)   # uint64 bit patterns; sums wrap alike
-    tr.bind_tally_tensor(tally)
+    # uint64 bit patterns as int64 (sums wrap alike); two buffers when a collective follows the trace,
+    # so that the all-reduce of one step can run beside the trace of the next
+    overlap = use_dist and args.backend == "nccl" and not args.no_overlap
+    tallies = [torch.zeros(tr.nwords, dtype=torch.int64, device=dev) for _ in range(2 if overlap else 1)]
+    pending = [None] * len(tallies)
+    tr.bind_tally_tensor(tallies[0])
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(idx, timed_slot=None):
+        b = idx % len(tallies)
+        tally = tallies[b]
+        if pending[b] is not None:          # the all-reduce that last used this buffer (two steps ago)
+            pending[b].wait()
+            pending[b] = None
+        if len(tallies) > 1:
+            tr.bind_tally_tensor(tally)
         tr.reset()
         begin = (idx * world + rank) * n_per_gpu
         if timed_slot is not None:
@@ -130,16 +152,24 @@ def main():
         tr.trace(args.seed, begin, n_per_gpu)
         if timed_slot is not None:
             stops[timed_slot].record(stream)
-        if args.backend == "gloo" and world > 1:        # rehearsal path: stage through the host
+        if not use_dist:
+            return
+        if args.backend == "gloo":                      # rehearsal path: stage through the host
             host = tally.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             tally.copy_(host)
+        elif overlap:                                   # ONE RCCL all-reduce, beside the next step's trace
+            pending[b] = dist.all_reduce(tally, op=dist.ReduceOp.SUM, async_op=True)
         else:
-            rt.distributed.allreduce_tallies(tally)      # ONE RCCL all-reduce; no-op at world size 1
+            dist.all_reduce(tally, op=dist.ReduceOp.SUM)
 
     def fence():
+        for b, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[b] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,7 +181,7 @@ def main():
         step(args.warmup + k, timed_slot=k)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -161,7 +191,7 @@ def main():
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
     # sanity on the last step's result (after the all-reduce every rank holds the node total)
-    words = tally.cpu().numpy()
+    words = tallies[(args.warmup + args.steps - 1) % len(tallies)].cpu().numpy()
     t = rt.split_tally_words(words, scene.itot, scene.jtot, scene.ktot)
     launched = int(t["toa_down"].sum())
     balance = rt.photon_balance(t)
@@ -188,7 +218,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{desc}; 2^{log2n} photons per GPU per step; "
                                    f"grid {scene.itot}x{scene.jtot}x{scene.ktot}; zenith {scene.zenith_deg} deg, "
-                                   f"albedo {scene.albedo}; step = reset + trace" + (" + RCCL all-reduce of tallies" if world > 1 else ""),
+                                   f"albedo {scene.albedo}; step = reset + trace" + ((" + RCCL all-reduce of tallies" if args.backend == "nccl" else " + gloo all-reduce staged through the host (rehearsal)") if use_dist else "")
+                                   + (" (all-reduce of step k beside the trace of step k+1, double-buffered)" if overlap else ""),
                        "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -210,7 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)
     tr.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
