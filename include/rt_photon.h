@@ -125,7 +125,6 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
  *                    pass over the columns rotated by a per-pass random offset (stands in for the
  *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
- *   "t_iters"        majorant regions a photon may cross within one traverse round of the pool kernel
  *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round
  *   "chunk"          photon IDs a wave of the pool kernel takes at a time from the device-wide cursor
  *                    (power of two, default 256; halved for small jobs until every wave finds work)

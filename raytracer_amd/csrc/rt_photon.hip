@@ -51,8 +51,8 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 constexpr int kBlock = 256;
-// device words behind rt_context::d_events: RT_N_EVENTS counters, RT_N_SCHED scheduler statistics,
-// and (on a cache line of its own) the photon-ID cursor of the pool kernel
+// device words behind rt_context::d_events: RT_N_EVENTS counters, RT_N_SCHED scheduler statistics and,
+// on a cache line of its own, the photon-ID cursor of the pool kernel
 constexpr int kCursorWord = 32;
 constexpr int kEventWords = 48;
 
@@ -82,16 +82,31 @@ struct TraceArgs
     float hx, hy, hz, inv_hx, inv_hy, zc0, zc1;
     int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
     int th_launch;            // pool kernel: waiting launches that trigger a launch round
-    int t_iters;              // pool kernel: majorant regions a photon may cross in one traverse round
     // stratified launch (launch_log2k >= 0): 2^k consecutive photon IDs per column, columns in
     // row-major order, each pass over the columns rotated by a per-pass random offset
     int launch_log2k;
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
-    // pool kernel: photon IDs are handed out in chunks of `chunk` from a device-wide cursor, so
-    // the launch needs no static partition (waves that start late or run slower simply take fewer)
+    const struct LaunchBlock* launch;         // pool kernel: see LaunchBlock
+    // pool kernel: photon IDs are handed out in chunks from this device-wide cursor, so the launch
+    // needs no static partition (waves that start late or run slower simply take fewer chunks)
     unsigned long long* cursor;
+};
+
+// What only the launch (regeneration) stage and the surface event of the pool kernel need. It lives
+// in device memory, not in the kernel arguments, so that these values are fetched where they are
+// used instead of occupying scalar registers through every round of the wave's loop (the loop
+// is short of SGPRs; every spilled one costs a v_readlane per use). Read-only while the tracer runs
+// (the cursor sits elsewhere: a line that takes atomics must not also serve these loads). Written by
+// rt_launch_block_kernel on the stream before each pool launch.
+struct LaunchBlock
+{
+    uint64_t pid_begin, total;
     uint32_t chunk;
+    int launch_log2k;
+    float sun_x, sun_y, sun_z, inv_sun_x, inv_sun_y, inv_sun_z;
+    float ztop, dx, dy, albedo;
+    uint32_t div_itot_mul, div_itot_shift;
 };
 
 __device__ __forceinline__ void tally_add(unsigned long long* p)
@@ -116,21 +131,30 @@ __device__ __forceinline__ uint32_t launch_pass_offset(uint64_t pass, uint32_t n
 }
 
 // Column (i, j) of rotated column index c: row-major, division by itot through the host's magic number.
+__device__ __forceinline__ void launch_column(uint32_t div_mul, uint32_t div_shift, uint32_t itot, uint32_t c,
+                                              uint32_t& i, uint32_t& j)
+{
+    j = (uint32_t)(((uint64_t)c * div_mul) >> div_shift);
+    i = c - j * itot;
+}
 __device__ __forceinline__ void launch_column(const TraceArgs& a, uint32_t c, uint32_t& i, uint32_t& j)
 {
-    j = (uint32_t)(((uint64_t)c * a.div_itot_mul) >> a.div_itot_shift);
-    i = c - j * (uint32_t)a.itot;
+    launch_column(a.div_itot_mul, a.div_itot_shift, (uint32_t)a.itot, c, i, j);
 }
 
-// Exact (slow) form of the stratified column of one photon ID: 64-bit division per photon.
+// Stratified column of one photon ID: 64-bit division per photon.
+__device__ __forceinline__ uint32_t launch_column_index_exact(int log2k, uint32_t ncol, uint64_t pid, uint32_t key0, uint32_t key1)
+{
+    const uint64_t qt = pid >> log2k;
+    const uint64_t pass = qt / ncol;
+    const uint32_t q = (uint32_t)(qt - pass * ncol);
+    uint32_t c = q + launch_pass_offset(pass, ncol, key0, key1);      // < 2 * ncol < 2^32
+    if (c >= ncol) c -= ncol;
+    return c;
+}
 __device__ __forceinline__ uint32_t launch_column_index_exact(const TraceArgs& a, uint64_t pid, uint32_t key0, uint32_t key1)
 {
-    const uint64_t qt = pid >> a.launch_log2k;
-    const uint64_t pass = qt / a.ncol;
-    const uint32_t q = (uint32_t)(qt - pass * a.ncol);
-    uint32_t c = q + launch_pass_offset(pass, a.ncol, key0, key1);      // < 2 * ncol < 2^32
-    if (c >= a.ncol) c -= a.ncol;
-    return c;
+    return launch_column_index_exact(a.launch_log2k, a.ncol, pid, key0, key1);
 }
 
 enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5, ST_REFLECT = 6 };
@@ -515,24 +539,17 @@ rt_trace_pool_kernel(const TraceArgs a)
     uint32_t* const st = rec + NS * kPoolRec;                   // state words (padded to kHalves*64)
     uint32_t* const sel = st + kHalves * 64;                    // 64 selected slots
 
-    // photon IDs of this wave: chunks [wave_next, wave_end) taken from the device-wide cursor
-    const uint64_t total = a.pid_end - a.pid_begin;
-    uint64_t wave_next = 0, wave_end = 0;
+    // photon IDs of this wave: wave_left IDs from wave_next on, a chunk taken from the device-wide cursor
+    uint64_t wave_next = 0;
+    uint32_t wave_left = 0;
     bool exhausted = false;
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
-    const float ztop = a.zface[a.nslab];
 
 #pragma unroll
     for (int h = 0; h < kHalves; ++h)
         st[h * 64 + lane] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
     int n_t = 0, n_e = 0, n_s = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
-
-    // stratified launch: column-order position of wave_next, kept incrementally (fast path for
-    // grids of >= 128 columns, where one round of <= 64 launches wraps the column index at most once)
-    const bool strat_fast = a.launch_log2k >= 0 && a.ncol >= 128u;
-    uint64_t qt0 = 0, pass_cur = 0;
-    uint32_t q_cur = 0, off_cur = 0, off_next = 0;
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
@@ -695,7 +712,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 {
                     // surface: absorb or reflect, raytracer_kernels.cu:463-486
                     RW(15) = pid_hi | (nev << 8);
-                    if (u01(w.x) <= a.albedo)
+                    if (u01(w.x) <= a.launch->albedo)
                     {
                         tally_add(&a.tallies[4u * a.ncol + cell]);
                         RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
@@ -709,12 +726,15 @@ rt_trace_pool_kernel(const TraceArgs a)
         else if (cls == 3u)
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
-            if (wave_next == wave_end && !exhausted)
+            const LaunchBlock* const lb = a.launch;
+            if (wave_left == 0u && !exhausted)
             {
                 // next chunk of IDs: one returning atomic per chunk, broadcast from lane 0
+                const uint32_t chunk = lb->chunk;
+                const uint64_t total = lb->total;
                 unsigned long long c0 = 0;
                 if (lane == 0)
-                    c0 = __hip_atomic_fetch_add(a.cursor, (unsigned long long)a.chunk, __ATOMIC_RELAXED,
+                    c0 = __hip_atomic_fetch_add(a.cursor, (unsigned long long)chunk, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t c0_lo = __builtin_amdgcn_readfirstlane((uint32_t)c0);
                 const uint32_t c0_hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
@@ -723,51 +743,35 @@ rt_trace_pool_kernel(const TraceArgs a)
                     exhausted = true;
                 else
                 {
-                    wave_next = a.pid_begin + c0;
-                    wave_end = a.pid_begin + (c0 + a.chunk < total ? c0 + a.chunk : total);
-                    if (strat_fast)
-                    {
-                        qt0 = wave_next >> a.launch_log2k;
-                        pass_cur = qt0 / a.ncol;
-                        q_cur = (uint32_t)(qt0 - pass_cur * a.ncol);
-                        off_cur = launch_pass_offset(pass_cur, a.ncol, key0, key1);
-                        off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
-                    }
+                    wave_next = lb->pid_begin + c0;
+                    wave_left = total - c0 < (uint64_t)chunk ? (uint32_t)(total - c0) : chunk;
                 }
             }
-            const uint64_t my_pid = wave_next + (uint64_t)lane;
-            const bool go = active && my_pid < wave_end;
+            const bool go = active && (uint32_t)lane < wave_left;
             if (active && !exhausted)
                 ns = PS_LAUNCH;          // no ID left in this chunk: wait for the next one
             if (go)
             {
+                const uint64_t my_pid = wave_next + (uint64_t)lane;
                 const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, 0u, key0, key1);
                 float tau_new = free_path_tau(u01(w.z));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
+                const int log2k = lb->launch_log2k;
                 float x, y;
-                if (a.launch_log2k < 0)
+                if (log2k < 0)
                 {
                     x = a.xs * u01(w.x);
                     y = a.ys * u01(w.y);
                 }
                 else
                 {
-                    uint32_t c;
-                    if (strat_fast)
-                    {
-                        uint32_t q = q_cur + (uint32_t)((my_pid >> a.launch_log2k) - qt0);
-                        uint32_t o = off_cur;
-                        if (q >= a.ncol) { q -= a.ncol; o = off_next; }
-                        c = q + o;
-                        if (c >= a.ncol) c -= a.ncol;
-                    }
-                    else
-                        c = launch_column_index_exact(a, my_pid, key0, key1);
+                    const uint32_t c = launch_column_index_exact(log2k, a.ncol, my_pid, key0, key1);
                     uint32_t ic, jc;
-                    launch_column(a, c, ic, jc);
-                    x = fma_(u01(w.x), a.dx, (float)ic * a.dx);
-                    y = fma_(u01(w.y), a.dy, (float)jc * a.dy);
+                    launch_column(lb->div_itot_mul, lb->div_itot_shift, (uint32_t)a.itot, c, ic, jc);
+                    const float dx = lb->dx, dy = lb->dy;
+                    x = fma_(u01(w.x), dx, (float)ic * dx);
+                    y = fma_(u01(w.y), dy, (float)jc * dy);
                 }
                 const int slab = a.nslab - 1;
                 int ci = 0, cj = 0, ck = 0;
@@ -775,9 +779,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                 {
                     ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
                 }
-                R4(0) = make_float4(x, y, ztop, tau_new);
-                R4(1) = make_float4(a.sun_x, a.sun_y, a.sun_z, __uint_as_float(0u));
-                R4(2) = make_float4(a.inv_sun_x, a.inv_sun_y, a.inv_sun_z, 0.0f);
+                R4(0) = make_float4(x, y, lb->ztop, tau_new);
+                R4(1) = make_float4(lb->sun_x, lb->sun_y, lb->sun_z, __uint_as_float(0u));
+                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, lb->inv_sun_z, 0.0f);
                 R4(3) = make_float4(__uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)),
                                     __uint_as_float((uint32_t)ck | ((uint32_t)slab << 16)),
                                     __uint_as_float(pid_lo), __uint_as_float(pid_hi | (1u << 8)));
@@ -785,22 +789,10 @@ rt_trace_pool_kernel(const TraceArgs a)
                 tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
                 ns = PS_TRAVERSE;
             }
-            // advance the wave's ID cursor (and, stratified, its column cursor) by the lanes served
-            const uint64_t left = wave_end - wave_next;
-            wave_next += (uint64_t)n < left ? (uint64_t)n : left;
-            if (strat_fast)
-            {
-                const uint64_t qt1 = wave_next >> a.launch_log2k;
-                q_cur += (uint32_t)(qt1 - qt0);
-                qt0 = qt1;
-                if (q_cur >= a.ncol)
-                {
-                    q_cur -= a.ncol;
-                    ++pass_cur;
-                    off_cur = off_next;
-                    off_next = launch_pass_offset(pass_cur + 1, a.ncol, key0, key1);
-                }
-            }
+            // advance the wave's ID cursor by the lanes served
+            const uint32_t adv = (uint32_t)n < wave_left ? (uint32_t)n : wave_left;
+            wave_next += adv;
+            wave_left -= adv;
         }
         else
         {
@@ -819,10 +811,6 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const bool diffuse = (cks >> 24) & 1u;
                 ns = PS_TRAVERSE;
                 uint32_t w11 = RW(11);
-                // up to t_iters regions per round: a photon that only crossed a face goes on at once
-                // (saves the slot selection and the LDS round trip of a further round)
-                for (int it = 0; it < a.t_iters && ns == PS_TRAVERSE; ++it)
-                {
                 if (nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
                 {
                     tally_add(&a.events[RT_EV_ABORT]);
@@ -926,7 +914,6 @@ rt_trace_pool_kernel(const TraceArgs a)
                             }
                         }
                     }
-                }
                 }
                 R4(0) = make_float4(x, y, z, tau);
                 RW(7) = nstep;
@@ -1037,6 +1024,16 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
     }
 }
 
+// Stores the launch block of the next pool launch and rewinds the ID cursor, in stream order.
+__global__ void rt_launch_block_kernel(LaunchBlock* dst, const LaunchBlock src, unsigned long long* cursor)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        *dst = src;
+        *cursor = 0ull;
+    }
+}
+
 __global__ void rt_add_u64_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1092,11 +1089,11 @@ struct rt_context
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
     int th_launch = 32;               // pool kernel: free slots that trigger a launch round
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
-    int t_iters = 1;                  // pool kernel: regions crossed per traverse round (more was not faster)
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
+    LaunchBlock* d_launch = nullptr;
 
     bool have_optics = false, have_scene = false;
     std::vector<float> lev_max;
@@ -1256,6 +1253,7 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
     if (e == hipSuccess) e = hipMalloc(&c->d_cells, sizeof(float4) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
     if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * kEventWords);
+    if (e == hipSuccess) e = hipMalloc(&c->d_launch, sizeof(LaunchBlock));
     if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
     if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * kEventWords);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
@@ -1280,6 +1278,7 @@ int rt_destroy(rt_context* c)
     if (c->d_maj) (void)hipFree(c->d_maj);
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
+    if (c->d_launch) (void)hipFree(c->d_launch);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -1347,11 +1346,6 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     {
         if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
         c->launch_log2k = (int)value;
-    }
-    else if (!strcmp(name, "t_iters"))
-    {
-        if (value < 1 || value > 64) return fail(RT_ERR_ARG, "rt_set_option: t_iters %lld outside [1,64]", value);
-        c->t_iters = (int)value;
     }
     else if (!strcmp(name, "chunk"))
     {
@@ -1428,7 +1422,6 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
     a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
     a.th_launch = c->th_launch;
-    a.t_iters = c->t_iters;
     a.launch_log2k = c->launch_log2k;
     a.dx = c->dx; a.dy = c->dy;
     {
@@ -1443,8 +1436,6 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
     if (blocks > cap) blocks = cap;
 
-    if (c->pool > 0)
-        RT_HIP(hipMemsetAsync(c->d_events + kCursorWord, 0, sizeof(unsigned long long), c->stream));
     RT_HIP(hipEventRecord(c->ev_start, c->stream));
     const dim3 block(kBlock);
     if (c->pool > 0)
@@ -1462,8 +1453,17 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         // every resident wave still finds work
         uint32_t chunk = (uint32_t)c->chunk;
         while (chunk > 64u && count / chunk < 4u * pcap) chunk >>= 1;
+        LaunchBlock lb;
+        memset(&lb, 0, sizeof(lb));
+        lb.pid_begin = pid_begin; lb.total = count;
+        lb.chunk = chunk; lb.launch_log2k = c->launch_log2k;
+        lb.sun_x = a.sun_x; lb.sun_y = a.sun_y; lb.sun_z = a.sun_z;
+        lb.inv_sun_x = a.inv_sun_x; lb.inv_sun_y = a.inv_sun_y; lb.inv_sun_z = a.inv_sun_z;
+        lb.ztop = a.zface[a.nslab]; lb.dx = a.dx; lb.dy = a.dy; lb.albedo = a.albedo;
+        lb.div_itot_mul = a.div_itot_mul; lb.div_itot_shift = a.div_itot_shift;
+        a.launch = c->d_launch;
         a.cursor = c->d_events + kCursorWord;
-        a.chunk = chunk;
+        hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, c->d_launch, lb, a.cursor);
         uint64_t pblocks = (count + chunk - 1) / chunk;
         if (pblocks > pcap) pblocks = pcap;
         const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);

@@ -20,7 +20,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=0, chunk=512, t_iters=1, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=0, chunk=256, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
 run(base, 1)
 res = []
 if what == "thresholds":
@@ -41,9 +41,6 @@ elif what == "chunk":
 elif what == "launch":
     for lk, thl in ((-1, 32), (-1, 16), (-1, 48), (-1, 64), (-1, 96), (5, 32), (3, 32), (7, 32), (0, 32), (10, 32), (5, 64)):
         o = dict(base, pool=128, launch_log2k=lk, th_launch=thl); res.append((run(o, 5), lk, thl))
-elif what == "titers":
-    for ti in (1, 2, 3, 4, 6, 8):
-        o = dict(base, pool=128, t_iters=ti); res.append((run(o, 5), ti))
 elif what == "blocks":
     for b in (2, 3, 4, 5, 6, 7, 8, 10, 12):
         o = dict(base, blocks_per_cu=b); res.append((run(o), b))
