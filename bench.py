@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU sample")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--launch-log2k", type=int, default=5,
+                    help="stratified launch: 2^k consecutive photon IDs per column (-1 = uniform launch positions); "
+                         "used only when every GPU's batch is a whole number of passes over the columns")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend; gloo (tallies staged through host memory) only to rehearse "
                          "the multi-rank flow on a box with one GPU")
@@ -125,6 +128,13 @@ def main():
     tr = rt.PhotonTracer.from_scene(scene, device=local_rank)
     if args.blocks_per_cu:
         tr.set_option("blocks_per_cu", args.blocks_per_cu)
+    # Launch order: consecutive photon IDs sweep the columns of the domain top (the reference's launch is
+    # a scrambled Sobol sequence over the same square), which keeps the cells a wave gathers L2-resident.
+    # Every batch below is a whole number of such sweeps, so each step samples the domain top evenly.
+    launch_log2k = args.launch_log2k
+    if launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
+        launch_log2k = -1
+    tr.set_option("launch_log2k", launch_log2k)
     stream = torch.cuda.current_stream()
     tr.set_stream(stream.cuda_stream)
     # uint64 bit patterns as int64 (sums wrap alike); two buffers when a collective follows the trace,
@@ -220,7 +230,10 @@ def main():
                                    f"grid {scene.itot}x{scene.jtot}x{scene.ktot}; zenith {scene.zenith_deg} deg, "
                                    f"albedo {scene.albedo}; step = reset + trace" + ((" + RCCL all-reduce of tallies" if args.backend == "nccl" else " + gloo all-reduce staged through the host (rehearsal)") if use_dist else "")
                                    + (" (all-reduce of step k beside the trace of step k+1, double-buffered)" if overlap else ""),
-                       "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}"},
+                       "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}",
+                       "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, "
+                                  f"{n_per_gpu // ((scene.itot * scene.jtot) << launch_log2k)} sweeps of the domain top per GPU per step"
+                                  if launch_log2k >= 0 else "uniform random positions")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "rt_trace_pool_kernel", "kernel_ms": avg_kernel_ms,

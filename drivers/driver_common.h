@@ -37,6 +37,12 @@ struct Config
     std::string indir = ".", outdir = ".";
     int exponent = -1;
     bool fixed_dot = false;
+    // --launch=uniform (default) | auto | K: stratified launch, 2^K consecutive photon IDs per column
+    // (the library's "launch_log2k"; stands in for the reference's scrambled-Sobol launch positions).
+    // It samples the domain top evenly only over whole passes of ncol * 2^K photons per GPU; "auto"
+    // takes the largest K <= 5 for which the photon count allows that, else uniform.
+    int launch_log2k = -1;
+    bool launch_auto = false;
 };
 
 inline void die(const std::string& msg)
@@ -76,6 +82,12 @@ inline void parse_args(int argc, char** argv, Config& c)
             else if (key == "indir") c.indir = val;
             else if (key == "outdir") c.outdir = val;
             else if (key == "physics") c.fixed_dot = (val == "fixed");
+            else if (key == "launch")
+            {
+                if (val == "uniform") { c.launch_log2k = -1; c.launch_auto = false; }
+                else if (val == "auto") c.launch_auto = true;
+                else { c.launch_log2k = std::stoi(val); c.launch_auto = false; }
+            }
             else if (key == "zenith")
             {
                 c.zenith_deg.clear();
@@ -135,6 +147,16 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     std::cout << "Shooting " << n_photons << " photons (" << n_photons / (64 * 512) << " per thread) " << std::endl;
 
     const size_t ncol = (size_t)c.itot * c.jtot, ncell = ncol * c.ktot;
+    int launch_log2k = c.launch_log2k;
+    if (c.launch_auto)
+    {
+        launch_log2k = -1;
+        for (int k = 5; k >= 0 && launch_log2k < 0; --k)
+            if (n_photons % ((uint64_t)c.ngpus * (ncol << k)) == 0) launch_log2k = k;
+    }
+    else if (launch_log2k >= 0 && n_photons % ((uint64_t)c.ngpus * (ncol << launch_log2k)) != 0)
+        std::cerr << "Warning: --launch=" << launch_log2k << " covers the domain top evenly only for whole passes of "
+                  << (ncol << launch_log2k) << " photons per GPU" << std::endl;
     std::vector<rt_context*> ctx(c.ngpus, nullptr);
     auto t0 = std::chrono::high_resolution_clock::now();
     for (int g = 0; g < c.ngpus; ++g)
@@ -142,6 +164,7 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
         check(rt_create(g, c.itot, c.jtot, c.ktot, c.dx, c.dy, c.dz, &ctx[g]), "rt_create");
         check(rt_upload_optics(ctx[g], k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
         check(rt_set_option(ctx[g], "fixed_dot", c.fixed_dot), "rt_set_option");
+        check(rt_set_option(ctx[g], "launch_log2k", launch_log2k), "rt_set_option");
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     rt_slab_info slabs;

@@ -54,7 +54,9 @@ constexpr int kBlock = 256;
 // device words behind rt_context::d_events: RT_N_EVENTS counters, RT_N_SCHED scheduler statistics and,
 // on a cache line of its own, the photon-ID cursor of the pool kernel
 constexpr int kCursorWord = 32;
-constexpr int kEventWords = 48;
+constexpr int kCursorStride = 16;     // words between the cursors of two XCDs: a 128-byte line each
+constexpr int kXcds = 8;
+constexpr int kEventWords = kCursorWord + kXcds * kCursorStride;
 
 // ------------------------------------------------------------------------------------------
 // Kernel arguments of the tracer (by value: they live in SGPRs).
@@ -88,8 +90,11 @@ struct TraceArgs
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
     const struct LaunchBlock* launch;         // pool kernel: see LaunchBlock
-    // pool kernel: photon IDs are handed out in chunks from this device-wide cursor, so the launch
-    // needs no static partition (waves that start late or run slower simply take fewer chunks)
+    // pool kernel: photon IDs are handed out in chunks from device-wide cursors, so the launch needs
+    // no static partition (waves that start late or run slower simply take fewer chunks). One cursor
+    // per XCD (kCursorStride words apart), each over its own eighth of the ID range: with the
+    // stratified launch an XCD then sweeps its own band of columns and its private L2 keeps that band's
+    // cells; a wave whose XCD has run dry takes chunks from the next XCD's range.
     unsigned long long* cursor;
 };
 
@@ -102,6 +107,7 @@ struct TraceArgs
 struct LaunchBlock
 {
     uint64_t pid_begin, total;
+    uint64_t sub_size;        // IDs per XCD range (a multiple of chunk)
     uint32_t chunk;
     int launch_log2k;
     float sun_x, sun_y, sun_z, inv_sun_x, inv_sun_y, inv_sun_z;
@@ -109,10 +115,10 @@ struct LaunchBlock
     uint32_t div_itot_mul, div_itot_shift;
 };
 
-__device__ __forceinline__ void tally_add(unsigned long long* p)
+__device__ __forceinline__ void tally_add(unsigned long long* p, unsigned long long v = 1ull)
 {
     // no-return 64-bit global atomic (write_photon_out, raytracer_kernels.cu:256-261)
-    __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // distance along the ray to a face; small negative (past the face by rounding) -> 0;
@@ -543,6 +549,9 @@ rt_trace_pool_kernel(const TraceArgs a)
     uint64_t wave_next = 0;
     uint32_t wave_left = 0;
     bool exhausted = false;
+    // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on; ranges of XCDs found empty so far
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kXcds - 1);
+    uint32_t ranges_dry = 0;
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
 
@@ -727,29 +736,37 @@ rt_trace_pool_kernel(const TraceArgs a)
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
             const LaunchBlock* const lb = a.launch;
-            if (wave_left == 0u && !exhausted)
+            while (wave_left == 0u && !exhausted)
             {
-                // next chunk of IDs: one returning atomic per chunk, broadcast from lane 0
+                // next chunk of IDs from this XCD's range (or the next range that has any left): one
+                // returning atomic per chunk, broadcast from lane 0
                 const uint32_t chunk = lb->chunk;
-                const uint64_t total = lb->total;
+                const uint64_t total = lb->total, sub = lb->sub_size;
+                const uint32_t x = (xcc + ranges_dry) & (kXcds - 1);
+                const uint64_t sub_lo = (uint64_t)x * sub;
+                const uint64_t sub_hi = sub_lo + sub < total ? sub_lo + sub : total;
                 unsigned long long c0 = 0;
                 if (lane == 0)
-                    c0 = __hip_atomic_fetch_add(a.cursor, (unsigned long long)chunk, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
+                    c0 = __hip_atomic_fetch_add(a.cursor + x * kCursorStride, (unsigned long long)chunk,
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t c0_lo = __builtin_amdgcn_readfirstlane((uint32_t)c0);
                 const uint32_t c0_hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
-                c0 = ((unsigned long long)c0_hi << 32) | c0_lo;
-                if (c0 >= total)
-                    exhausted = true;
+                c0 = (((unsigned long long)c0_hi << 32) | c0_lo) + sub_lo;
+                if (sub_lo >= total || c0 >= sub_hi)
+                {
+                    if (++ranges_dry == (uint32_t)kXcds)
+                        exhausted = true;
+                }
                 else
                 {
                     wave_next = lb->pid_begin + c0;
-                    wave_left = total - c0 < (uint64_t)chunk ? (uint32_t)(total - c0) : chunk;
+                    wave_left = sub_hi - c0 < (uint64_t)chunk ? (uint32_t)(sub_hi - c0) : chunk;
                 }
             }
             const bool go = active && (uint32_t)lane < wave_left;
             if (active && !exhausted)
                 ns = PS_LAUNCH;          // no ID left in this chunk: wait for the next one
+            uint32_t toa_col = 0xffffffffu;
             if (go)
             {
                 const uint64_t my_pid = wave_next + (uint64_t)lane;
@@ -786,8 +803,22 @@ rt_trace_pool_kernel(const TraceArgs a)
                                     __uint_as_float((uint32_t)ck | ((uint32_t)slab << 16)),
                                     __uint_as_float(pid_lo), __uint_as_float(pid_hi | (1u << 8)));
                 const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                tally_add(&a.tallies[(uint32_t)i + (uint32_t)j * (uint32_t)a.itot]);
+                toa_col = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
                 ns = PS_TRAVERSE;
+            }
+            // TOA-down tally. Stratified launch puts runs of consecutive lanes into one column: the
+            // first lane of a run adds the run's length (one atomic per run instead of one per photon).
+            {
+                const uint32_t prev_col = (uint32_t)__shfl_up((int)toa_col, 1);
+                const bool leader = go && (lane == 0 || prev_col != toa_col);
+                const unsigned long long lm = __ballot(leader);
+                const int n_go = __popcll(__ballot(go));
+                if (leader)
+                {
+                    const unsigned long long above = lane == 63 ? 0ull : lm >> (lane + 1);
+                    const int next = above ? lane + 1 + __builtin_ctzll(above) : n_go;
+                    tally_add(&a.tallies[toa_col], (unsigned long long)(next - lane));
+                }
             }
             // advance the wave's ID cursor by the lanes served
             const uint32_t adv = (uint32_t)n < wave_left ? (uint32_t)n : wave_left;
@@ -1024,14 +1055,15 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
     }
 }
 
-// Stores the launch block of the next pool launch and rewinds the ID cursor, in stream order.
+// Stores the launch block of the next pool launch and rewinds the ID cursors, in stream order.
 __global__ void rt_launch_block_kernel(LaunchBlock* dst, const LaunchBlock src, unsigned long long* cursor)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-    {
+    if (blockIdx.x != 0)
+        return;
+    if (threadIdx.x == 0)
         *dst = src;
-        *cursor = 0ull;
-    }
+    if (threadIdx.x < kXcds)
+        cursor[threadIdx.x * kCursorStride] = 0ull;
 }
 
 __global__ void rt_add_u64_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t n)
@@ -1456,6 +1488,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         LaunchBlock lb;
         memset(&lb, 0, sizeof(lb));
         lb.pid_begin = pid_begin; lb.total = count;
+        lb.sub_size = (((count + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
         lb.chunk = chunk; lb.launch_log2k = c->launch_log2k;
         lb.sun_x = a.sun_x; lb.sun_y = a.sun_y; lb.sun_z = a.sun_z;
         lb.inv_sun_x = a.inv_sun_x; lb.inv_sun_y = a.inv_sun_y; lb.inv_sun_z = a.inv_sun_z;

@@ -65,3 +65,20 @@ def test_file_input_driver_and_zenith_sweep(tmp_path):
         got = _read(tmp_path / f"zenith_{zen:02d}", sc)
         for n in TALLY_NAMES:
             assert np.array_equal(got[n], want[n]), (zen, n)
+
+
+def test_stratified_launch_option_of_the_drivers(tmp_path):
+    """--launch=auto picks the largest K <= 5 with whole passes of ncol * 2^K photons; --launch=K is explicit."""
+    sc = scenes.tiny()
+    sc.write(str(tmp_path))
+    ncol = sc.itot * sc.jtot
+    dims = [f"--itot={sc.itot}", f"--jtot={sc.jtot}", f"--ktot={sc.ktot}", f"--dx={sc.dx}", f"--dy={sc.dy}", f"--dz={sc.dz}"]
+    n = 1 << 16
+    k_auto = max((k for k in range(6) if n % (ncol << k) == 0), default=-1)
+    for arg, k in (("--launch=auto", k_auto), ("--launch=2", 2), ("--launch=uniform", -1)):
+        r = subprocess.run([IO, "16", "--seed=5", arg, *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        want, _ = O.photon_oracle(sc, 5, 0, n, launch_log2k=k)
+        got = _read(tmp_path, sc)
+        for name in TALLY_NAMES:
+            assert np.array_equal(got[name], want[name]), (arg, name)

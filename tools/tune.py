@@ -4,6 +4,8 @@ one process, median of kernel times). Usage: python tools/tune.py c4 24 [what]""
 import itertools, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
+if os.environ.get("RT_TUNE_LIB"):      # an experimental build of the library (tools only)
+    rt.tracer.LIB_PATH = os.path.abspath(os.environ["RT_TUNE_LIB"])
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
@@ -20,7 +22,10 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=0, chunk=256, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=128, chunk=256, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
+    if "=" in kv:
+        base[kv.split("=")[0]] = int(kv.split("=")[1])
 run(base, 1)
 res = []
 if what == "thresholds":
@@ -35,6 +40,11 @@ elif what == "pool":
 elif what == "pool2":
     for pl, b in ((64, 32), (64, 24), (96, 23), (96, 20), (96, 16), (128, 32), (128, 18), (128, 16), (128, 14), (128, 12), (160, 14), (160, 12), (192, 12), (192, 10), (256, 8)):
         o = dict(base, pool=pl, pool_waves_per_cu=b); res.append((run(o), pl, b))
+elif what == "launch2":
+    for lk in (-1, 3, 5, 6, 7, 8):
+        o = dict(base, pool=128, launch_log2k=lk); res.append((run(o, 3), lk))
+elif what == "one":
+    o = dict(base, pool=128); res.append((run(o, 5), "default"))
 elif what == "chunk":
     for ch in (64, 128, 256, 512, 1024, 2048, 4096, 16384):
         o = dict(base, pool=128, chunk=ch); res.append((run(o, 5), ch))
