@@ -39,7 +39,12 @@ WORKLOADS = {
     "c4": ("cumulus_c4", 28, "C4 LES cumulus 1024x1024x128 (2^31 photons per step over 8 GPUs)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_GLANEOPS = 78643.2   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane per clock
+# The ceilings this kernel actually meets, measured on MI355X with tools/gather_rate.hip and
+# tools/valu_rate.hip (outputs: profiles/r1_microbench_*.txt): sectors of a multi-GiB array gathered at
+# random, random 64-bit atomics, and wave64 VALU instructions (2 cycles each at 256 CU x 4 SIMD x 2.4 GHz).
+GATHER_PEAK_G = 54.7
+ATOMIC_PEAK_G = 18.2
+VALU_PEAK_GWAVEINST = 1228.8
 
 
 def parse():
@@ -247,8 +252,25 @@ def main():
             try:
                 with open(prof) as fh:
                     p = json.load(fh)
-                if p.get("photons_per_launch") == n_per_gpu:
+                if p.get("photons_per_launch") == n_per_gpu and p.get("launch_log2k", -1) == launch_log2k:
                     out["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+                    # the same profile's counters priced against the measured gather and VALU ceilings
+                    kt = avg_kernel_ms * 1e-3
+                    if p.get("fabric_reads_per_photon") is not None:
+                        misses = p["fabric_reads_per_photon"] * n_per_gpu
+                        atomics = p.get("atomics_per_photon", 0.0) * n_per_gpu
+                        out["gather_roofline"] = {
+                            "bound": "random 64-byte sector reads and 64-bit atomics (measured ceilings, G/s)",
+                            "sector_reads_per_photon": p["fabric_reads_per_photon"],
+                            "atomics_per_photon": p.get("atomics_per_photon"),
+                            "peak_sector_reads_G_per_s": GATHER_PEAK_G, "peak_atomics_G_per_s": ATOMIC_PEAK_G,
+                            "frac": (misses / GATHER_PEAK_G + atomics / ATOMIC_PEAK_G) * 1e-9 / kt}
+                    if p.get("valu_wave_insts_per_photon") is not None:
+                        out["valu_roofline"] = {
+                            "wave_insts_per_photon": p["valu_wave_insts_per_photon"],
+                            "active_lanes": p.get("active_lanes_per_valu_inst"),
+                            "peak_G_wave_insts_per_s": VALU_PEAK_GWAVEINST,
+                            "frac": p["valu_wave_insts_per_photon"] * n_per_gpu / kt / 1e9 / VALU_PEAK_GWAVEINST}
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,7 @@ miss), so no doubling is applied here."""
 import collections, csv, glob, json, os, shutil, sys
 
 tag, workload, photons = sys.argv[1], sys.argv[2], int(sys.argv[3])
+launch_log2k = int(sys.argv[4]) if len(sys.argv) > 4 else -1     # bench.py --launch-log2k of the profiled run
 src = f"gpurun_out/prof_{tag}"
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"{here}/{tag}_kernel_stats.csv")
@@ -34,7 +35,14 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_INSTS_VALU" in pmc:
     pmc["active_lanes_per_valu_inst"] = pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"]
     pmc["valu_wave_insts_per_photon"] = pmc["SQ_INSTS_VALU"] / photons
+pmc["launch_log2k"] = launch_log2k
+if "FETCH_SIZE" in pmc:
+    pmc["fabric_reads_per_photon"] = pmc["FETCH_SIZE"] * 1024 / 64 / photons      # 64-byte read requests
+if "TCC_EA0_ATOMIC_sum" in pmc:
+    pmc["atomics_per_photon"] = pmc["TCC_EA0_ATOMIC_sum"] / photons
 json.dump(pmc, open(f"{here}/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
-json.dump({"photons_per_launch": photons, "hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "source": f"profiles/{tag}_pmc.json"},
+keys = ("photons_per_launch", "launch_log2k", "hbm_bytes_per_launch", "fabric_reads_per_photon", "atomics_per_photon",
+        "valu_wave_insts_per_photon", "active_lanes_per_valu_inst", "kernel_avg_ns")
+json.dump(dict({k: pmc.get(k) for k in keys}, source=f"profiles/{tag}_pmc.json"),
           open(f"{here}/pmc_{workload}.json", "w"), indent=1)
 print(json.dumps(pmc, indent=1, sort_keys=True))
