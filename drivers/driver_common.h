@@ -9,6 +9,7 @@
 
 #include "../include/rt_photon.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -43,6 +44,7 @@ struct Config
     // takes the largest K <= 5 for which the photon count allows that, else uniform.
     int launch_log2k = -1;
     bool launch_auto = false;
+    bool input_f64 = false;                   // sidecar says the data files hold float64
 };
 
 inline void die(const std::string& msg)
@@ -55,6 +57,74 @@ inline void check(int rc, const char* what)
 {
     if (rc != RT_OK)
         die(std::string(what) + ": " + rt_last_error());
+}
+
+inline std::string trimmed(const std::string& t)
+{
+    const size_t b = t.find_first_not_of(" \t\r\n");
+    if (b == std::string::npos) return "";
+    return t.substr(b, t.find_last_not_of(" \t\r\n") - b + 1);
+}
+
+// The directory given by --indir= (default "."): needed before the other options are parsed.
+inline std::string find_indir(int argc, char** argv)
+{
+    std::string dir = ".";
+    for (int i = 1; i < argc; ++i)
+    {
+        const std::string a = argv[i];
+        if (a.rfind("--indir=", 0) == 0) dir = a.substr(8);
+    }
+    return dir;
+}
+
+// Sidecar <indir>/grid.hdr (`key = value` lines, written by raytracer_amd.scenes.write_sidecar /
+// python -m raytracer_amd.convert): dimensions, spacings and dtype of the headerless data files, which
+// raytracer_3d_io.cu:11-17 compiles in. Absent file: the defaults stand. Command-line options parsed
+// afterwards override it. Returns whether a sidecar was read.
+inline bool read_sidecar(const std::string& dir, Config& c)
+{
+    std::ifstream f(dir + "/grid.hdr");
+    if (!f) return false;
+    std::string line;
+    int lineno = 0;
+    while (std::getline(f, line))
+    {
+        ++lineno;
+        line = trimmed(line.substr(0, line.find('#')));
+        if (line.empty()) continue;
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) die("grid.hdr:" + std::to_string(lineno) + ": expected `key = value`");
+        const std::string key = trimmed(line.substr(0, eq)), val = trimmed(line.substr(eq + 1));
+        try
+        {
+            if (key == "itot") c.itot = std::stoi(val);
+            else if (key == "jtot") c.jtot = std::stoi(val);
+            else if (key == "ktot") c.ktot = std::stoi(val);
+            else if (key == "dx") c.dx = std::stof(val);
+            else if (key == "dy") c.dy = std::stof(val);
+            else if (key == "dz") c.dz = std::stof(val);
+            else if (key == "albedo") c.albedo = std::stof(val);
+            else if (key == "zenith_deg") c.zenith_deg = {std::stod(val)};
+            else if (key == "azimuth_deg") c.azimuth_deg = std::stod(val);
+            else if (key == "dtype")
+            {
+                if (val == "float64") c.input_f64 = true;
+                else if (val == "float32") c.input_f64 = false;
+                else die("grid.hdr:" + std::to_string(lineno) + ": dtype " + val + ": float32 or float64");
+            }
+            else if (key == "order")
+            {
+                if (val != "kji") die("grid.hdr:" + std::to_string(lineno) + ": only order = kji is supported");
+            }
+            else die("grid.hdr:" + std::to_string(lineno) + ": unknown key " + key);
+        }
+        catch (const std::logic_error&)
+        {
+            die("grid.hdr:" + std::to_string(lineno) + ": cannot parse value \"" + val + "\"");
+        }
+    }
+    return true;
 }
 
 // argv: exactly one positional (the exponent n, raytracer_3d.cu:209-215) plus --key=value options.
@@ -119,6 +189,24 @@ inline void save_binary(const std::string& dir, const std::string& name, const v
     std::ofstream f(dir + "/" + name + ".bin", std::ios::out | std::ios::trunc | std::ios::binary);
     if (!f) throw std::runtime_error("Cannot write file \"" + name + ".bin\"");
     f.write(reinterpret_cast<const char*>(ptr), count * sizeof(uint64_t));
+}
+
+// float64 data files (sidecar dtype = float64) are narrowed to float32, the tracer's arithmetic type.
+inline void load_binary_f64(const std::string& dir, const std::string& name, float* ptr, size_t count)
+{
+    std::ifstream f(dir + "/" + name + ".bin", std::ios::in | std::ios::binary);
+    if (!f) throw std::runtime_error("Cannot read file \"" + name + ".bin\"");
+    std::vector<double> buf(1 << 16);
+    size_t done = 0;
+    while (done < count)
+    {
+        const size_t n = std::min(buf.size(), count - done);
+        f.read(reinterpret_cast<char*>(buf.data()), n * sizeof(double));
+        if (static_cast<size_t>(f.gcount()) != n * sizeof(double))
+            throw std::runtime_error("File \"" + name + ".bin\" is shorter than itot*jtot*ktot float64 values");
+        for (size_t i = 0; i < n; ++i) ptr[done + i] = static_cast<float>(buf[i]);
+        done += n;
+    }
 }
 
 inline void load_binary(const std::string& dir, const std::string& name, float* ptr, size_t count)

@@ -48,28 +48,104 @@ class Scene:
     def fields(self):
         return self.k_gas, self.k_cloud, self.ssa, self.asy
 
-    def write(self, directory: str) -> None:
-        """Write the four input files of the raytracer_3d_io flow (raytracer_3d_io.cu:54-57)."""
+    def write(self, directory: str, sidecar: bool = True, dtype=np.float32) -> None:
+        """Write the four input files of the raytracer_3d_io flow (raytracer_3d_io.cu:54-57) and, unless
+        sidecar=False, the header file grid.hdr next to them (the data files themselves stay headerless,
+        so the reference's own executable still reads them)."""
         os.makedirs(directory, exist_ok=True)
         for name, arr in (("k_ext_gas", self.k_gas), ("k_ext_cloud", self.k_cloud),
                           ("ssa", self.ssa), ("asy", self.asy)):
-            np.ascontiguousarray(arr, dtype=np.float32).tofile(os.path.join(directory, name + ".bin"))
+            np.ascontiguousarray(arr, dtype=dtype).tofile(os.path.join(directory, name + ".bin"))
+        if sidecar:
+            write_sidecar(directory, self.itot, self.jtot, self.ktot, self.dx, self.dy, self.dz,
+                          dtype=np.dtype(dtype).name, albedo=self.albedo, zenith_deg=self.zenith_deg,
+                          azimuth_deg=self.azimuth_deg)
 
     @staticmethod
-    def read(directory: str, itot: int, jtot: int, ktot: int, dx: float, dy: float, dz: float,
-             name: str = "from_files", **kw) -> "Scene":
-        """Load the four headerless float32 files; the size must match exactly (the reference
-        over-reads by 2x and relies on EOF, raytracer_3d_io.cu:41 — not reproduced)."""
+    def read(directory: str, itot: int = None, jtot: int = None, ktot: int = None, dx: float = None,
+             dy: float = None, dz: float = None, name: str = "from_files", **kw) -> "Scene":
+        """Load the four headerless files; the size must match exactly (the reference over-reads by 2x
+        and relies on EOF, raytracer_3d_io.cu:41 — not reproduced). Dimensions and spacings come from
+        the arguments or, for those left out, from the sidecar grid.hdr (which may also say that the
+        files hold float64; they are narrowed to float32 as the tracer computes in float32)."""
+        hdr = read_sidecar(directory)
+        given = dict(itot=itot, jtot=jtot, ktot=ktot, dx=dx, dy=dy, dz=dz)
+        for key, val in given.items():
+            if val is None:
+                if key not in hdr:
+                    raise RuntimeError(f"Scene.read: {key} not given and no grid.hdr in {directory} provides it")
+                given[key] = hdr[key]
+        itot, jtot, ktot = int(given["itot"]), int(given["jtot"]), int(given["ktot"])
+        dtype = np.dtype(hdr.get("dtype", "float32"))
+        for key in ("albedo", "zenith_deg", "azimuth_deg"):
+            if key in hdr and key not in kw:
+                kw[key] = float(hdr[key])
         n = itot * jtot * ktot
         arrs = []
         for fname in ("k_ext_gas", "k_ext_cloud", "ssa", "asy"):
             path = os.path.join(directory, fname + ".bin")
             if not os.path.exists(path):
                 raise RuntimeError(f'Cannot read file "{fname}.bin"')   # raytracer_3d_io.cu:44
-            if os.path.getsize(path) != 4 * n:
-                raise RuntimeError(f'File "{fname}.bin" has {os.path.getsize(path)} bytes, expected {4*n}')
-            arrs.append(np.fromfile(path, dtype=np.float32).reshape(ktot, jtot, itot))
-        return Scene(name, itot, jtot, ktot, dx, dy, dz, *arrs, **kw)
+            if os.path.getsize(path) != dtype.itemsize * n:
+                raise RuntimeError(f'File "{fname}.bin" has {os.path.getsize(path)} bytes, expected {dtype.itemsize*n}')
+            arrs.append(np.fromfile(path, dtype=dtype).reshape(ktot, jtot, itot).astype(np.float32))
+        return Scene(name, itot, jtot, ktot, float(given["dx"]), float(given["dy"]), float(given["dz"]), *arrs, **kw)
+
+
+SIDECAR = "grid.hdr"
+_SIDECAR_INT = ("itot", "jtot", "ktot")
+_SIDECAR_FLOAT = ("dx", "dy", "dz", "albedo", "zenith_deg", "azimuth_deg")
+
+
+def write_sidecar(directory: str, itot: int, jtot: int, ktot: int, dx: float, dy: float, dz: float,
+                  dtype: str = "float32", **extra) -> str:
+    """grid.hdr: `key = value` lines describing the four headerless data files beside it — what
+    raytracer_3d_io.cu:11-17 fixes at compile time. Read by Scene.read and by drivers/raytracer_3d_io_gpu."""
+    if dtype not in ("float32", "float64"):
+        raise ValueError(f"sidecar dtype {dtype!r}: float32 or float64")
+    path = os.path.join(directory, SIDECAR)
+    with open(path, "w") as fh:
+        fh.write("# sidecar of k_ext_gas.bin k_ext_cloud.bin ssa.bin asy.bin: headerless, C order [k][j][i]\n")
+        for key, val in (("itot", itot), ("jtot", jtot), ("ktot", ktot)):
+            fh.write(f"{key} = {int(val)}\n")
+        for key, val in (("dx", dx), ("dy", dy), ("dz", dz)):
+            fh.write(f"{key} = {float(val)!r}\n")
+        fh.write(f"dtype = {dtype}\norder = kji\n")
+        for key, val in extra.items():
+            if key not in _SIDECAR_FLOAT:
+                raise ValueError(f"sidecar key {key!r} unknown")
+            fh.write(f"{key} = {float(val)!r}\n")
+    return path
+
+
+def read_sidecar(directory: str) -> dict:
+    """Parse grid.hdr ({} if absent). Unknown keys and malformed lines are errors, not ignored."""
+    path = os.path.join(directory, SIDECAR)
+    if not os.path.exists(path):
+        return {}
+    out = {}
+    with open(path) as fh:
+        for lineno, line in enumerate(fh, 1):
+            line = line.split("#", 1)[0].strip()
+            if not line:
+                continue
+            if "=" not in line:
+                raise RuntimeError(f"{path}:{lineno}: expected `key = value`")
+            key, val = (t.strip() for t in line.split("=", 1))
+            if key in _SIDECAR_INT:
+                out[key] = int(val)
+            elif key in _SIDECAR_FLOAT:
+                out[key] = float(val)
+            elif key == "dtype":
+                if val not in ("float32", "float64"):
+                    raise RuntimeError(f"{path}:{lineno}: dtype {val!r}: float32 or float64")
+                out[key] = val
+            elif key == "order":
+                if val != "kji":
+                    raise RuntimeError(f"{path}:{lineno}: order {val!r}: only kji (C order [k][j][i]) is supported")
+            else:
+                raise RuntimeError(f"{path}:{lineno}: unknown key {key!r}")
+    return out
 
 
 def _mix(k_gas, ssa_gas, asy_gas, k_cloud, ssa_cloud, asy_cloud):

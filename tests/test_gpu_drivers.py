@@ -82,3 +82,20 @@ def test_stratified_launch_option_of_the_drivers(tmp_path):
         got = _read(tmp_path, sc)
         for name in TALLY_NAMES:
             assert np.array_equal(got[name], want[name]), (arg, name)
+
+
+def test_io_driver_reads_the_sidecar_header(tmp_path):
+    """f3: with grid.hdr beside the data files the driver needs no --itot/--dx options; float64 files work."""
+    sc = scenes.tiny()
+    sc.zenith_deg = 35.0
+    sc.write(str(tmp_path), dtype=np.float64)
+    r = subprocess.run([IO, "16", "--seed=8"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want, _ = O.photon_oracle(sc, 8, 0, 1 << 16)
+    got = _read(tmp_path, sc)
+    for n in TALLY_NAMES:
+        assert np.array_equal(got[n], want[n]), n
+    with open(tmp_path / "grid.hdr", "a") as fh:
+        fh.write("colour = blue\n")
+    r = subprocess.run([IO, "16"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "unknown key colour" in r.stderr

@@ -66,3 +66,65 @@ def test_cumulus_generator_is_deterministic_and_periodic():
     assert np.array_equal(a.k_cloud, b.k_cloud) and (a.k_cloud > 0).any()
     assert np.all(a.asy[a.k_cloud == 0] == 0) and np.all(a.asy[a.k_cloud > 0] > 0)
     assert np.all((a.ssa > 0) & (a.ssa <= 1))
+
+
+def test_sidecar_header_round_trip_and_float64_files(tmp_path):
+    """f3: grid.hdr carries what raytracer_3d_io.cu:11-17 compiles in; the data files stay headerless."""
+    sc = scenes.tiny()
+    sc.albedo, sc.zenith_deg = 0.35, 30.0
+    sc.write(str(tmp_path))
+    hdr = scenes.read_sidecar(str(tmp_path))
+    assert (hdr["itot"], hdr["jtot"], hdr["ktot"]) == (sc.itot, sc.jtot, sc.ktot)
+    assert (hdr["dx"], hdr["dy"], hdr["dz"], hdr["dtype"]) == (sc.dx, sc.dy, sc.dz, "float32")
+    back = scenes.Scene.read(str(tmp_path))                       # nothing but the directory
+    assert (back.itot, back.jtot, back.ktot, back.dx, back.dy, back.dz) == (sc.itot, sc.jtot, sc.ktot, sc.dx, sc.dy, sc.dz)
+    assert (back.albedo, back.zenith_deg, back.azimuth_deg) == (0.35, 30.0, sc.azimuth_deg)
+    for a, b in zip(sc.fields(), back.fields()):
+        assert np.array_equal(a, b)
+    # arguments override the sidecar (and a wrong one is caught by the size check)
+    with pytest.raises(RuntimeError, match="bytes"):
+        scenes.Scene.read(str(tmp_path), ktot=sc.ktot + 1)
+    # float64 files are narrowed to float32
+    d64 = tmp_path / "f64"
+    sc.write(str(d64), dtype=np.float64)
+    assert os.path.getsize(d64 / "ssa.bin") == 8 * sc.ncell
+    back64 = scenes.Scene.read(str(d64))
+    for a, b in zip(sc.fields(), back64.fields()):
+        assert b.dtype == np.float32 and np.array_equal(a, b)
+    # headerless flow still works, and without a sidecar the dimensions must be given
+    bare = tmp_path / "bare"
+    sc.write(str(bare), sidecar=False)
+    assert not os.path.exists(bare / "grid.hdr")
+    with pytest.raises(RuntimeError, match="grid.hdr"):
+        scenes.Scene.read(str(bare))
+    with open(tmp_path / "grid.hdr", "a") as fh:
+        fh.write("colour = blue\n")
+    with pytest.raises(RuntimeError, match="unknown key"):
+        scenes.read_sidecar(str(tmp_path))
+
+
+def test_converter_follows_make_binary(tmp_path):
+    """python -m raytracer_amd.convert: slice one g-point of [gpt, z, y, x] variables, patch a band of
+    levels the way make_binary.py:11-12 does (asy := 0, ssa := ssa of the level below the band), dump
+    headerless float32 [k][j][i] + sidecar."""
+    from raytracer_amd import convert
+    rng = np.random.default_rng(5)
+    shape = (3, 12, 5, 7)                                          # gpt, z, y, x
+    nc = {"kext_cloud": rng.random(shape), "kext_gas": rng.random(shape), "ssa": rng.random(shape), "g": rng.random(shape)}
+    np.savez(tmp_path / "fields.npz", **nc)
+    convert.main([str(tmp_path / "fields.npz"), "--outdir", str(tmp_path / "out"), "--dx", "100", "--dy", "100",
+                  "--dz", "30", "--gpt", "2", "--patch-levels", "6:9"])
+    sc = scenes.Scene.read(str(tmp_path / "out"))
+    assert (sc.itot, sc.jtot, sc.ktot, sc.dx, sc.dz) == (7, 5, 12, 100.0, 30.0)
+    # what make_binary.py would have written, step by step
+    asy = nc["g"][2].copy(); ssa = nc["ssa"][2].copy()
+    asy[6:9, :, :] = 0
+    ssa[6:9, :, :] = ssa[5, :, :]
+    for got, want in ((sc.k_cloud, nc["kext_cloud"][2]), (sc.k_gas, nc["kext_gas"][2]), (sc.ssa, ssa), (sc.asy, asy)):
+        assert np.array_equal(got, want.astype(np.float32))
+    raw = np.fromfile(tmp_path / "out" / "asy.bin", dtype=np.float32)
+    assert raw.size == 12 * 5 * 7 and raw[3 + 2 * 7 + 4 * 35] == np.float32(asy[4, 2, 3])
+    with pytest.raises(ValueError, match="gpt"):
+        convert.to_scene(nc, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="netCDF4|expected"):
+        convert.load_fields(str(tmp_path / "missing.nc"))
