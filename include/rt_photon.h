@@ -116,6 +116,10 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
 /* Options by name:
  *   "fixed_dot"      0 (default): dot() as the reference writes it, raytracer_kernels.cu:70-74;
  *                    1: the mathematically intended v1.z*v2.z
+ *   "planar"         1: the scattering rule of the reference's 2D tracer, src/raytracer.cpp:360-364 and
+ *                    :280-282 — directions stay in the x-z plane (a scattering turns the direction by
+ *                    +-acos(mu) in that plane, the surface reflects to (+-mu, 0, sqrt(1-mu^2))). With
+ *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
  *                    (default 8, 8, 4; 0 = slab majorants only, the reference's scheme)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /

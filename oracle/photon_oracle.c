@@ -207,6 +207,10 @@ typedef struct
     int sx, sy, sz; /* supervoxel size in cells for the majorant grid of the cloud slab; 0 = none */
     int launch_log2k; /* < 0: launch positions uniform over the domain (one Philox draw per axis);
                          >= 0: stratified by column, 2^launch_log2k consecutive photon IDs per column */
+    int planar; /* 1: the scattering rule of the reference's 2D tracer — directions stay in the x-z plane:
+                   a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
+                   surface reflects to (+-mu, 0, sqrt(1-mu^2)) (raytracer.cpp:280-282); the signs are the top
+                   bit of the draw that is the azimuth in 3D. Meant for jtot = 1 and azimuth = 0. */
 } oracle_scene_t;
 
 /* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
@@ -489,11 +493,20 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                     {
                         bump(&t->sfc_up[ij]);
                         const float mu = sqrtf(u01(w[1]));
+                        if (sc->planar)
+                        {
+                            ux = u01(w[2]) >= 0.5f ? mu : -mu;
+                            uy = 0.0f;
+                            uz = sqrtf(fmaf(-mu, mu, 1.0f));
+                        }
+                        else
+                        {
                         float sa, ca;
                         oracle_sincos2pi(u01(w[2]), &sa, &ca);
                         ux = mu * sa;
                         uy = mu * ca;
                         uz = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
+                        }
                         iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
                         diffuse = 1;
                     }
@@ -540,6 +553,19 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             const int from_cloud = r * kt < s_scat * k_cloud[c];
             if (from_cloud) ++ev[EV_CSCAT];
             const float mu = from_cloud ? henyey_mu(asy[c], u01(w[2])) : rayleigh_mu(u01(w[2]));
+            if (sc->planar)
+            {
+                /* in-plane rotation by +-theta: sin/cos of (+-acos(mu) + atan2(ux, uz)) of raytracer.cpp:360-364
+                 * expanded with the angle-sum formulas, so no inverse trigonometry is needed */
+                const float sn2 = sqrtf(fmaxf(fmaf(-mu, mu, 1.0f), 0.0f));
+                const float ssn = u01(w[3]) >= 0.5f ? sn2 : -sn2;
+                const float nx = fmaf(mu, ux, ssn * uz);
+                const float nz = fmaf(mu, uz, -(ssn * ux));
+                ux = nx; uy = 0.0f; uz = nz;
+                iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                diffuse = 1;
+                continue;
+            }
             /* raytracer_kernels.cu:523. In float the inverse CDFs can return |mu| a few ulp
              * above 1, which makes the radicand negative (NaN direction in the reference);
              * clamped at 0 here (SURVEY.md §7 "float edge cases"). */

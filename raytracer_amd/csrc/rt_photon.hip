@@ -89,6 +89,7 @@ struct TraceArgs
     int launch_log2k;
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
+    int planar;               // pool kernel: scattering rule of the reference's 2D tracer (directions stay in x-z)
     const struct LaunchBlock* launch;         // pool kernel: see LaunchBlock
     // pool kernel: photon IDs are handed out in chunks from device-wide cursors, so the launch needs
     // no static partition (waves that start late or run slower simply take fewer chunks). One cursor
@@ -608,9 +609,34 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, -}
                 const uint32_t cks = RW(13);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
-                float sp, cp;
-                rt_sincos2pi(g2.z, sp, cp);
-                if (state == PS_SCATTER)
+                float sp = 0.0f, cp = 0.0f;
+                if (!a.planar)
+                    rt_sincos2pi(g2.z, sp, cp);
+                if (a.planar)
+                {
+                    // the 2D tracer's rules (raytracer.cpp:360-364, 280-282): turn the direction by
+                    // +-acos(mu) within the x-z plane (angle-sum formulas instead of acos/atan2/sin/cos),
+                    // reflect to (+-mu, 0, sqrt(1 - mu^2)); the sign is the top bit of the azimuth draw
+                    const bool plus = g2.z >= 0.5f;
+                    if (state == PS_SCATTER)
+                    {
+                        const bool from_cloud = (cks >> 25) & 1u;
+                        const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
+                        const float sn2 = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f), 0.0f));
+                        const float ssn = plus ? sn2 : -sn2;
+                        const float nx = fma_(mu, ux, ssn * uz);
+                        const float nz = fma_(mu, uz, -(ssn * ux));
+                        ux = nx; uz = nz;
+                    }
+                    else
+                    {
+                        const float mu = __builtin_sqrtf(g2.y);
+                        ux = plus ? mu : -mu;
+                        uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f));
+                    }
+                    uy = 0.0f;
+                }
+                else if (state == PS_SCATTER)
                 {
                     // phase function + rotation, raytracer_kernels.cu:520-548
                     const bool from_cloud = (cks >> 25) & 1u;
@@ -1120,6 +1146,7 @@ struct rt_context
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
     int th_launch = 32;               // pool kernel: free slots that trigger a launch round
+    bool planar = false;                // 2D tracer's scattering rule (pool kernel only)
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     unsigned long long* d_tallies = nullptr;
@@ -1363,6 +1390,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     if (!c || !name) return fail(RT_ERR_ARG, "rt_set_option: null argument");
     if (!strcmp(name, "fixed_dot")) c->fixed_dot = value != 0;
     else if (!strcmp(name, "stats")) c->stats = value != 0;
+    else if (!strcmp(name, "planar")) c->planar = value != 0;
     else if (!strcmp(name, "blocks_per_cu"))
     {
         if (value < 1 || value > 16) return fail(RT_ERR_ARG, "rt_set_option: blocks_per_cu %lld outside [1,16]", value);
@@ -1455,6 +1483,9 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
     a.th_launch = c->th_launch;
     a.launch_log2k = c->launch_log2k;
+    a.planar = c->planar ? 1 : 0;
+    if (c->planar && c->pool == 0)
+        return fail(RT_ERR_ARG, "rt_trace: option planar needs the pool kernel (pool > 0)");
     a.dx = c->dx; a.dy = c->dy;
     {
         // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)

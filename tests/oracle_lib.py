@@ -27,7 +27,7 @@ class OracleScene(C.Structure):
                 ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
                 ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
                 ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int),
-                ("launch_log2k", C.c_int)]
+                ("launch_log2k", C.c_int), ("planar", C.c_int)]
 
 
 class OracleSlabs(C.Structure):
@@ -93,20 +93,20 @@ def new_tallies(scene):
 DEFAULT_SUPERGRID = (8, 8, 4)     # must equal the product's default (rt_set_option "supergrid_*")
 
 
-def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1) -> OracleScene:
+def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False) -> OracleScene:
     f = np.float32
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
-                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k))
+                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar))
 
 
 def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False,
-                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1):
+                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False):
     """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
     t = tallies if tallies is not None else new_tallies(scene)
     ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
-    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k)
+    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar)
     fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
                                    seed, pid_begin, count, nthreads,
@@ -198,3 +198,59 @@ def balance(t) -> int:
     out = int(t["surface_down_direct"].sum()) + int(t["surface_down_diffuse"].sum()) - int(t["surface_up"].sum()) \
         + int(t["toa_up"].sum()) + int(t["atmos_direct"].sum()) + int(t["atmos_diffuse"].sum())
     return inn - out
+
+
+# ---- 2D tracer (reference src/raytracer.cpp) -------------------------------
+REF2D_BIN = os.path.join(ROOT, "oracle", "_ref", "raytracer_2d_ref")
+TALLY_NAMES_2D = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up", "atmos")
+
+
+def block_cloud_2d_f64():
+    """The built-in scene of raytracer.cpp:126-173 in double precision, value for value (its cloud mask
+    tests the lower cell edges i*dx, k*dx, not the centres)."""
+    itot, ktot, dx = 256, 128, 25.0
+    k_ext_gas, ssa_gas, asy_gas = 1.0e-4, 0.5, 0.0
+    k_ext_cloud, ssa_cloud, asy_cloud = 5.0e-3, 0.9, 0.85
+    k_gas = np.full((ktot, itot), k_ext_gas)
+    k_cloud = np.zeros((ktot, itot))
+    ssa = np.full((ktot, itot), ssa_gas)
+    asy = np.zeros((ktot, itot))
+    xi = np.arange(itot) * dx
+    zk = np.arange(ktot) * dx
+    mask = ((zk > 1000) & (zk < 1500.))[:, None] & ((xi > 4000) & (xi < 5000))[None, :]
+    k_cloud[mask] = k_ext_cloud
+    ssa[mask] = (ssa_gas * k_ext_gas + ssa_cloud * k_ext_cloud) / (k_ext_gas + k_ext_cloud)
+    asy[mask] = (asy_gas * ssa_gas * k_ext_gas + asy_cloud * ssa_cloud * k_ext_cloud) / (ssa_gas * k_ext_gas + ssa_cloud * k_ext_cloud)
+    return dict(itot=itot, ktot=ktot, dx=dx, k_gas=k_gas, k_cloud=k_cloud, ssa=ssa, asy=asy,
+                albedo=0.2, zenith_rad=50. * (np.pi / 180.))
+
+
+def cpu_ref_2d(s, n_photons, nthreads=1, serial_seed=False):
+    """Run oracle/cpu_ref_2d.cpp; returns (tallies dict with the six 2D names, events[8])."""
+    itot, ktot = s["itot"], s["ktot"]
+    t = {n: np.zeros((ktot, itot) if n == "atmos" else (itot,), dtype=np.uint64) for n in TALLY_NAMES_2D}
+    ev = np.zeros(8, dtype=np.uint64)
+    arrs = [np.ascontiguousarray(s[k], dtype=np.float64) for k in ("k_gas", "k_cloud", "ssa", "asy")]
+    fn = lib().cpu_ref2d_trace
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_int] \
+        + [C.c_void_p] * 7
+    rc = fn(itot, ktot, s["dx"], *[a.ctypes.data for a in arrs], s["albedo"], s["zenith_rad"],
+            n_photons, nthreads, int(serial_seed), *[t[n].ctypes.data for n in TALLY_NAMES_2D], ev.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"cpu_ref2d_trace failed: {rc}")
+    return t, ev
+
+
+def run_reference_binary_2d(arg: int, workdir: str, nthreads: int = 1):
+    """Run the compiled reference (oracle/_ref/raytracer_2d_ref <arg>) in workdir; returns its six tallies."""
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    subprocess.run([REF2D_BIN, str(arg)], cwd=workdir, check=True, env=env, stdout=subprocess.DEVNULL)
+    return {n: np.fromfile(os.path.join(workdir, n + ".bin"), dtype=np.uint64).reshape((128, 256) if n == "atmos" else (256,))
+            for n in TALLY_NAMES_2D}
+
+
+def balance_2d(t) -> int:
+    """Photon balance of plot_results.py:27-31 (must be exactly 0)."""
+    return int(t["toa_down"].sum()) - (int(t["surface_down_direct"].sum()) + int(t["surface_down_diffuse"].sum())
+                                       - int(t["surface_up"].sum()) + int(t["toa_up"].sum()) + int(t["atmos"].sum()))

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GPU = os.path.join(ROOT, "drivers", "raytracer_3d_gpu")
 IO = os.path.join(ROOT, "drivers", "raytracer_3d_io_gpu")
+GPU2D = os.path.join(ROOT, "drivers", "raytracer_gpu")
 
 
 def _read(d, sc):
@@ -99,3 +100,25 @@ def test_io_driver_reads_the_sidecar_header(tmp_path):
         fh.write("colour = blue\n")
     r = subprocess.run([IO, "16"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "unknown key colour" in r.stderr
+
+
+def test_2d_driver_writes_what_plot_results_reads(tmp_path):
+    """f4: raytracer_gpu <multiple of 100 000> — CLI of raytracer.cpp:424-433, the six files of :416-421 read the
+    way plot_results.py:17-23 reads them, counts bit-identical to the planar oracle."""
+    from test_oracle_2d import scene_2d
+    r = subprocess.run([GPU2D], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Add the multiple of 100,000 photons as an argument!" in r.stdout
+    r = subprocess.run([GPU2D, "3", "--seed=4"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert any(l.startswith("Duration: ") and l.endswith("(s)") for l in r.stdout.splitlines())
+    itot, ktot = 256, 128
+    atmos = np.fromfile(tmp_path / "atmos.bin", dtype=np.uint64).reshape((ktot, itot))       # plot_results.py:23
+    rows = {n: np.fromfile(tmp_path / f"{n}.bin", dtype=np.uint64) for n in TALLY_NAMES[:5]}
+    assert all(v.shape == (itot,) for v in rows.values())
+    want, _ = O.photon_oracle(scene_2d(), 4, 0, 300000, planar=True)
+    for n in TALLY_NAMES[:5]:
+        assert np.array_equal(rows[n], want[n][0]), n
+    assert np.array_equal(atmos, (want["atmos_direct"] + want["atmos_diffuse"])[:, 0, :])
+    balance = int(rows["toa_down"].sum()) - (int(rows["surface_down_direct"].sum()) + int(rows["surface_down_diffuse"].sum())
+                                             - int(rows["surface_up"].sum()) + int(rows["toa_up"].sum()) + int(atmos.sum()))
+    assert balance == 0                                                                       # plot_results.py:27-31

@@ -179,6 +179,24 @@ def test_chunked_id_distribution_does_not_change_results(rt, chunk, n):
     tr.close()
 
 
+@pytest.mark.parametrize("n,supergrid", [(1 << 18, (8, 8, 4)), (1 << 17, (4, 1, 2)), (50_001, None)])
+def test_planar_mode_bit_identical_to_oracle(rt, n, supergrid):
+    """the 2D tracer as the jtot = 1 grid with the in-plane scattering rule (option planar)."""
+    from test_oracle_2d import scene_2d
+    scene = scene_2d()
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, planar=1)
+    tr.set_supergrid(*(supergrid or (0, 0, 0)))
+    tr.trace(17, 3_000_000_000, n); tr.synchronize()
+    want, ev = O.photon_oracle(scene, 17, 3_000_000_000, n, supergrid=supergrid, planar=True)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev
+    tr.close()
+    lane = rt.PhotonTracer.from_scene(scene, planar=1, pool=0)
+    with pytest.raises(rt.RtError, match="planar"):
+        lane.trace(1, 0, 10)
+    lane.close()
+
+
 def test_frozen_golden_vector(rt):
     import os
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "photon_oracle_tiny.npz"))
