@@ -270,6 +270,7 @@ def main():
                             "wave_insts_per_photon": p["valu_wave_insts_per_photon"],
                             "active_lanes": p.get("active_lanes_per_valu_inst"),
                             "peak_G_wave_insts_per_s": VALU_PEAK_GWAVEINST,
+                            "sustained_by_microbenchmark_G_wave_insts_per_s": 1040.0,   # v_xor_b32, 8 waves/SIMD
                             "frac": p["valu_wave_insts_per_photon"] * n_per_gpu / kt / 1e9 / VALU_PEAK_GWAVEINST}
             except Exception:
                 pass
