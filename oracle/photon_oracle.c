@@ -35,6 +35,7 @@
  *   cloud slab bounds ........ raytracer_kernels.cu:263-305  (its four indexing bugs not kept)
  */
 
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -331,12 +332,21 @@ static inline void bump(uint64_t* p)
     ++*p;
 }
 
-/* distance along the ray (in units of the direction vector) to a face; a small negative value
- * (already past the face by rounding) -> 0; NaN or -infinity (zero direction component) -> infinity */
+/* Reciprocal of a direction component as the traversal keeps it: finite (+-FLT_MAX for a zero
+ * component); its sign — not the component's — says which face of a region the photon heads for, so
+ * (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component (a Lambert azimuth
+ * draw of exactly 0 makes ux = +0). */
+static inline float dir_reciprocal(float u)
+{
+    return fminf(fmaxf(1.0f / u, -FLT_MAX), FLT_MAX);
+}
+
+/* distance along the ray (in units of the direction vector) to the face the photon heads for; a
+ * negative value (already past the face by rounding) -> 0 */
 static inline float face_distance(float face, float pos, float inv_u)
 {
     const float t = (face - pos) * inv_u;
-    return t >= 0.0f ? t : (t > -INFINITY ? 0.0f : INFINITY);
+    return t > 0.0f ? t : 0.0f;
 }
 
 /* Draw layout: ONE Philox block per event, counter = (pid_lo, pid_hi, event index, 0):
@@ -394,7 +404,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
     if (!(tau > 0.0f)) tau = 0.0f;
     float z = sl->zface[sl->nslab];
     float ux = sl->sun[0], uy = sl->sun[1], uz = sl->sun[2];
-    float iux = 1.0f / ux, iuy = 1.0f / uy, iuz = 1.0f / uz;
+    float iux = dir_reciprocal(ux), iuy = dir_reciprocal(uy), iuz = dir_reciprocal(uz);
     int slab = sl->nslab - 1;
     int ci = 0, cj = 0, ck = 0;
     if (slab == g) { ci = cell_of(x, inv_hx, nci); cj = cell_of(y, inv_hy, ncj); ck = nck - 1; }
@@ -418,19 +428,19 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         float M, invM, tx, ty, tz, fz;
         const float xlo = (float)ci * hx, xhi = (ci + 1 == nci) ? xs : (float)(ci + 1) * hx;
         const float ylo = (float)cj * hy, yhi = (cj + 1 == ncj) ? ys : (float)(cj + 1) * hy;
-        const float fx = ux > 0.0f ? xhi : xlo, fy = uy > 0.0f ? yhi : ylo;
+        const float fx = iux > 0.0f ? xhi : xlo, fy = iuy > 0.0f ? yhi : ylo;
         if (gridded)
         {
             const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
             M = sl->maj[2 * e]; invM = sl->maj[2 * e + 1];
             const float zlo = fmaf((float)ck, hz, zc0), zhi = (ck + 1 == nck) ? zc1 : fmaf((float)(ck + 1), hz, zc0);
-            fz = uz > 0.0f ? zhi : zlo;
+            fz = iuz > 0.0f ? zhi : zlo;
             tx = face_distance(fx, x, iux); ty = face_distance(fy, y, iuy); tz = face_distance(fz, z, iuz);
         }
         else
         {
             M = sl->kmaj[slab]; invM = sl->inv_kmaj[slab];
-            fz = uz > 0.0f ? sl->zface[slab + 1] : sl->zface[slab];
+            fz = iuz > 0.0f ? sl->zface[slab + 1] : sl->zface[slab];
             tx = INFINITY; ty = INFINITY; tz = face_distance(fz, z, iuz);
         }
         float t_exit = tx; int axis = 0;
@@ -450,20 +460,20 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             int leave = 0;                       /* +1: leaves the slab upwards, -1: downwards */
             if (axis == 0)
             {
-                x = fx; ci += ux > 0.0f ? 1 : -1;
+                x = fx; ci += iux > 0.0f ? 1 : -1;
                 if (ci == nci) { ci = 0; x = 0.0f; }
                 if (ci < 0) { ci = nci - 1; x = xs; }
             }
             else if (axis == 1)
             {
-                y = fy; cj += uy > 0.0f ? 1 : -1;
+                y = fy; cj += iuy > 0.0f ? 1 : -1;
                 if (cj == ncj) { cj = 0; y = 0.0f; }
                 if (cj < 0) { cj = ncj - 1; y = ys; }
             }
             else
             {
                 z = fz;
-                const int up = uz > 0.0f;
+                const int up = iuz > 0.0f;
                 if (gridded)
                 {
                     const int nk = ck + (up ? 1 : -1);
@@ -507,7 +517,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                         uy = mu * ca;
                         uz = sqrtf(fmaf(-mu, mu, 1.0f) + RT_EPS);
                         }
-                        iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                        iux = dir_reciprocal(ux); iuy = dir_reciprocal(uy); iuz = dir_reciprocal(uz);
                         diffuse = 1;
                     }
                     else
@@ -562,7 +572,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                 const float nx = fmaf(mu, ux, ssn * uz);
                 const float nz = fmaf(mu, uz, -(ssn * ux));
                 ux = nx; uy = 0.0f; uz = nz;
-                iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                iux = dir_reciprocal(ux); iuy = dir_reciprocal(uy); iuz = dir_reciprocal(uz);
                 diffuse = 1;
                 continue;
             }
@@ -598,7 +608,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             const float ny = fmaf(mu, uy, sn * fmaf(sp, oy, cp * by));
             const float nz = fmaf(mu, uz, sn * fmaf(sp, oz, cp * bz));
             ux = nx; uy = ny; uz = nz;
-            iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+            iux = dir_reciprocal(ux); iuy = dir_reciprocal(uy); iuz = dir_reciprocal(uz);
             diffuse = 1;
         }
         else

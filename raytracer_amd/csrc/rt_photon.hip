@@ -21,6 +21,7 @@
 #include "rt_device.hip.h"
 #include "../../include/rt_photon.h"
 
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -122,12 +123,19 @@ __device__ __forceinline__ void tally_add(unsigned long long* p, unsigned long l
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// distance along the ray to a face; small negative (past the face by rounding) -> 0;
-// NaN or -infinity (zero direction component) -> infinity
+// Reciprocal of a direction component as the traversal stores it: finite (+-FLT_MAX for a zero
+// component), and its sign — not the component's — says which face of a region the photon heads for,
+// so that (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component.
+__device__ __forceinline__ float dir_reciprocal(float u)
+{
+    return __builtin_fminf(__builtin_fmaxf(1.0f / u, -3.402823466e+38f), 3.402823466e+38f);
+}
+
+// distance along the ray to the face the photon heads for; negative (past the face by rounding) -> 0
 __device__ __forceinline__ float face_distance(float face, float pos, float inv_u)
 {
     const float t = (face - pos) * inv_u;
-    return t >= 0.0f ? t : (t > -__builtin_inff() ? 0.0f : __builtin_inff());
+    return t > 0.0f ? t : 0.0f;
 }
 
 // Rotation of pass p of the stratified launch: a Philox draw keyed on the pass index.
@@ -271,7 +279,7 @@ rt_trace_kernel(const TraceArgs a)
                     uy = mu * cp;
                     uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
-                iux = 1.0f / ux; iuy = 1.0f / uy; iuz = 1.0f / uz;
+                iux = dir_reciprocal(ux); iuy = dir_reciprocal(uy); iuz = dir_reciprocal(uz);
                 diffuse = true;
                 state = ST_TRAVERSE;
             }
@@ -396,10 +404,10 @@ rt_trace_kernel(const TraceArgs a)
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
                     // the face ahead on each axis: index of the cell face, then its coordinate
-                    const int cfx = ci + (ux > 0.0f ? 1 : 0), cfy = cj + (uy > 0.0f ? 1 : 0);
+                    const int cfx = ci + (iux > 0.0f ? 1 : 0), cfy = cj + (iuy > 0.0f ? 1 : 0);
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
-                    const bool up = uz > 0.0f;
+                    const bool up = iuz > 0.0f;
                     float fz;
                     if (gridded)
                     {
@@ -434,13 +442,13 @@ rt_trace_kernel(const TraceArgs a)
                         int leave = 0;
                         if (axis == 0)
                         {
-                            x = fx; ci += ux > 0.0f ? 1 : -1;
+                            x = fx; ci += iux > 0.0f ? 1 : -1;
                             if (ci == a.nci) { ci = 0; x = 0.0f; }
                             if (ci < 0) { ci = a.nci - 1; x = a.xs; }
                         }
                         else if (axis == 1)
                         {
-                            y = fy; cj += uy > 0.0f ? 1 : -1;
+                            y = fy; cj += iuy > 0.0f ? 1 : -1;
                             if (cj == a.ncj) { cj = 0; y = 0.0f; }
                             if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
                         }
@@ -520,8 +528,8 @@ rt_trace_kernel(const TraceArgs a)
 // resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
 // One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
 //
-// LDS per wave: NS records of four 16-byte groups (stored group-major), NS state words and a
-// 64-entry selection list:
+// LDS per wave: NS records of four 16-byte groups (stored group-major), NS state bytes and a
+// 64-entry selection list (bytes):
 //   g0 {x, y, z, tau}
 //   g1 {ux, uy, uz, nstep}
 //   g2 {1/ux, 1/uy, 1/uz, w}   w = 1/M of the region (traverse -> collision) or the surface column
@@ -539,12 +547,12 @@ rt_trace_pool_kernel(const TraceArgs a)
     using namespace rt;
     static_assert(NS % 32 == 0 && NS >= 64 && NS <= 256, "pool size");
     constexpr int kHalves = (NS + 63) / 64;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + kHalves * 64 + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + kHalves * 16 + 16];
 
     const int lane = threadIdx.x;
-    uint32_t* const rec = lds;                                  // NS records
-    uint32_t* const st = rec + NS * kPoolRec;                   // state words (padded to kHalves*64)
-    uint32_t* const sel = st + kHalves * 64;                    // 64 selected slots
+    uint32_t* const rec = lds;                                              // NS records
+    uint8_t* const st = reinterpret_cast<uint8_t*>(rec + NS * kPoolRec);    // state bytes (padded to kHalves*64)
+    uint8_t* const sel = st + kHalves * 64;                                 // 64 selected slots
 
     // photon IDs of this wave: wave_left IDs from wave_next on, a chunk taken from the device-wide cursor
     uint64_t wave_next = 0;
@@ -584,7 +592,7 @@ rt_trace_pool_kernel(const TraceArgs a)
             const unsigned long long m = __ballot(match);
             const int rank = found + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (match && rank < 64)
-                sel[rank] = sidx;
+                sel[rank] = (uint8_t)sidx;
             found += __popcll(m);
         }
         asm volatile("" ::: "memory");
@@ -675,7 +683,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
                 R4(1) = make_float4(ux, uy, uz, g1.w);
-                R4(2) = make_float4(1.0f / ux, 1.0f / uy, 1.0f / uz, 0.0f);
+                R4(2) = make_float4(dir_reciprocal(ux), dir_reciprocal(uy), dir_reciprocal(uz), 0.0f);
                 RW(13) = (cks | (1u << 24)) & ~(1u << 25);      // diffuse from now on
                 ns = PS_TRAVERSE;
             }
@@ -881,10 +889,10 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
-                    const int cfx = ci + (ux > 0.0f ? 1 : 0), cfy = cj + (uy > 0.0f ? 1 : 0);
+                    const int cfx = ci + (g2.x > 0.0f ? 1 : 0), cfy = cj + (g2.y > 0.0f ? 1 : 0);
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
-                    const bool up = uz > 0.0f;
+                    const bool up = g2.z > 0.0f;
                     float fz;
                     if (gridded)
                     {
@@ -919,13 +927,13 @@ rt_trace_pool_kernel(const TraceArgs a)
                         int leave = 0;
                         if (axis == 0)
                         {
-                            x = fx; ci += ux > 0.0f ? 1 : -1;
+                            x = fx; ci += g2.x > 0.0f ? 1 : -1;
                             if (ci == a.nci) { ci = 0; x = 0.0f; }
                             if (ci < 0) { ci = a.nci - 1; x = a.xs; }
                         }
                         else if (axis == 1)
                         {
-                            y = fy; cj += uy > 0.0f ? 1 : -1;
+                            y = fy; cj += g2.y > 0.0f ? 1 : -1;
                             if (cj == a.ncj) { cj = 0; y = 0.0f; }
                             if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
                         }
@@ -984,7 +992,7 @@ rt_trace_pool_kernel(const TraceArgs a)
 #undef RW
         // ---- publish the new states and update the stage counts ----
         if (active)
-            st[slot] = ns;
+            st[slot] = (uint8_t)ns;
         const uint32_t ncls = active ? (ns >> 2) : 4u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
                   d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u));
@@ -1470,7 +1478,10 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
     a.albedo = c->albedo;
     a.sun_x = c->slabs.sun[0]; a.sun_y = c->slabs.sun[1]; a.sun_z = c->slabs.sun[2];
-    a.inv_sun_x = 1.0f / a.sun_x; a.inv_sun_y = 1.0f / a.sun_y; a.inv_sun_z = 1.0f / a.sun_z;
+    {
+        const auto rcp = [](float u) { return std::fmin(std::fmax(1.0f / u, -FLT_MAX), FLT_MAX); };   // dir_reciprocal
+        a.inv_sun_x = rcp(a.sun_x); a.inv_sun_y = rcp(a.sun_y); a.inv_sun_z = rcp(a.sun_z);
+    }
     a.nslab = c->slabs.nslab;
     for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
     a.maj = c->d_maj;
@@ -1507,7 +1518,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         const int ns = c->pool;
         if (a.pid_end > (1ull << 40))
             return fail(RT_ERR_ARG, "rt_trace: the pool kernel packs photon ids into 40 bits");
-        const size_t lds_bytes = ((size_t)ns * kPoolRec + (size_t)((ns + 63) / 64) * 64 + 64) * 4;
+        const size_t lds_bytes = ((size_t)ns * kPoolRec + (size_t)((ns + 63) / 64) * 16 + 16) * 4;
         int per_cu = (int)((160u * 1024u) / lds_bytes);
         if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
         if (per_cu < 1) per_cu = 1;
