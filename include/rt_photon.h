@@ -122,6 +122,9 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
  *                    (default 8, 8, 4; 0 = slab majorants only, the reference's scheme)
+ *   "levels"         cloud-free supervoxels are merged into aligned cubes of up to 2^levels supervoxels per
+ *                    edge, each crossed as one majorant region (0 = one region per supervoxel; default -1 =
+ *                    automatic: 3 if at least a third of the supervoxels then lie in merged regions, else 0)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change)
@@ -182,6 +185,11 @@ int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
 /* The majorant grid of the cloud slab as nck*ncj*nci pairs {M, 1/M}, [ck][cj][ci] (n_pairs must
  * equal nck*ncj*nci of rt_get_slabs). Test/diagnostic access; no counterpart in the reference. */
 int rt_get_majorants(rt_context* ctx, float* out_pairs, size_t n_pairs);
+
+/* The region level of every supervoxel, [ck][cj][ci] (n must equal nck*ncj*nci): its majorant region is the
+ * aligned cube of 2^level supervoxels per edge around it; rt_get_majorants returns the region's pair.
+ * Test/diagnostic access; no counterpart in the reference. */
+int rt_get_region_levels(rt_context* ctx, uint8_t* out, size_t n);
 
 /* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
  * but RT_EV_ABORT). Synchronises first. */

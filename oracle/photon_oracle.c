@@ -212,6 +212,10 @@ typedef struct
                    a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
                    surface reflects to (+-mu, 0, sqrt(1-mu^2)) (raytracer.cpp:280-282); the signs are the top
                    bit of the draw that is the azimuth in 3D. Meant for jtot = 1 and azimuth = 0. */
+    int levels; /* cloud-free supervoxels are merged into aligned cubes of up to 2^levels supervoxels per
+                   edge, each crossed as ONE majorant region (0 = every supervoxel is its own region; < 0 =
+                   automatic: 3 if at least a third of the supervoxels then lie in merged regions, else 0 —
+                   merging pays in sparse cloud fields and costs a little in dense ones) */
 } oracle_scene_t;
 
 /* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
@@ -229,10 +233,57 @@ typedef struct
     int gslab;          /* index of the gridded slab, -1 if none */
     int nci, ncj, nck;  /* supervoxels per axis */
     float hx, hy, hz;   /* supervoxel edge lengths */
-    float* maj;         /* nck*ncj*nci pairs {M, 1/M}; owned, freed by oracle_free_slabs */
+    float* maj;         /* nck*ncj*nci pairs {M, 1/M} of the REGION a supervoxel belongs to; owned,
+                           freed by oracle_free_slabs */
+    unsigned char* lvl; /* nck*ncj*nci region levels: the supervoxel's region is the aligned cube of 2^lvl
+                           supervoxels per edge that contains it (clipped at the grid) */
 } oracle_slabs_t;
 
-void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; }
+void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->lvl); s->lvl = NULL; }
+
+/* Region hierarchy over the supervoxel grid. A supervoxel without any cloud cell takes the largest
+ * level L <= max_level for which the whole aligned cube of 2^L supervoxels per edge around it (clipped
+ * at the grid) is cloud-free; all members of such a cube then share one region whose majorant is the
+ * maximum over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out. */
+static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, const unsigned char* cloudy,
+                          unsigned char* lvl)
+{
+    const size_t n = (size_t)nci * ncj * nck;
+    memset(lvl, 0, n);
+    for (int L = 1; L <= max_level; ++L)
+    {
+        const int sz = 1 << L;
+        for (int bk = 0; bk < nck; bk += sz)
+            for (int bj = 0; bj < ncj; bj += sz)
+                for (int bi = 0; bi < nci; bi += sz)
+                {
+                    const int k1 = bk + sz < nck ? bk + sz : nck, j1 = bj + sz < ncj ? bj + sz : ncj,
+                              i1 = bi + sz < nci ? bi + sz : nci;
+                    int clear = 1;
+                    float m = 0.0f;
+                    for (int k = bk; k < k1 && clear; ++k)
+                        for (int j = bj; j < j1 && clear; ++j)
+                            for (int i = bi; i < i1; ++i)
+                            {
+                                const size_t e = ((size_t)k * ncj + j) * nci + i;
+                                if (cloudy[e]) { clear = 0; break; }
+                                if (maj[2 * e] > m) m = maj[2 * e];
+                            }
+                    if (!clear) continue;
+                    /* members of a clear cube already carry the maximum over their (clear) sub-cubes, so
+                     * m is the maximum of the original values over the whole cube */
+                    for (int k = bk; k < k1; ++k)
+                        for (int j = bj; j < j1; ++j)
+                            for (int i = bi; i < i1; ++i)
+                            {
+                                const size_t e = ((size_t)k * ncj + j) * nci + i;
+                                lvl[e] = (unsigned char)L;
+                                maj[2 * e] = m;
+                                maj[2 * e + 1] = 1.0f / m;
+                            }
+                }
+    }
+}
 
 /* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
  * raytracer_3d_io.cu:60-77 (majorants), per slab: max over the slab's levels of gas + cloud. */
@@ -288,6 +339,7 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
 
     /* majorant grid of the cloud slab */
     out->gslab = -1; out->nci = out->ncj = out->nck = 0; out->hx = out->hy = out->hz = 0.0f; out->maj = NULL;
+    out->lvl = NULL;
     if (g >= 0 && sc->sx > 0 && sc->sy > 0 && sc->sz > 0)
     {
         const int nci = (sc->itot + sc->sx - 1) / sc->sx, ncj = (sc->jtot + sc->sy - 1) / sc->sy;
@@ -295,11 +347,14 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         out->gslab = g; out->nci = nci; out->ncj = ncj; out->nck = nck;
         out->hx = (float)sc->sx * sc->dx; out->hy = (float)sc->sy * sc->dy; out->hz = (float)sc->sz * sc->dz;
         out->maj = (float*)malloc(sizeof(float) * 2 * (size_t)nci * ncj * nck);
+        out->lvl = (unsigned char*)malloc((size_t)nci * ncj * nck);
+        unsigned char* cloudy = (unsigned char*)malloc((size_t)nci * ncj * nck);
         for (int ck = 0; ck < nck; ++ck)
             for (int cj = 0; cj < ncj; ++cj)
                 for (int ci = 0; ci < nci; ++ci)
                 {
                     float m = 0.0f;
+                    int any_cloud = 0;
                     const int k1 = k_lo + (ck + 1) * sc->sz < k_hi + 1 ? k_lo + (ck + 1) * sc->sz : k_hi + 1;
                     const int j1 = (cj + 1) * sc->sy < sc->jtot ? (cj + 1) * sc->sy : sc->jtot;
                     const int i1 = (ci + 1) * sc->sx < sc->itot ? (ci + 1) * sc->sx : sc->itot;
@@ -310,11 +365,27 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
                                 const size_t c = (size_t)i + (size_t)j * sc->itot + (size_t)k * nlev;
                                 const float kt = k_gas[c] + k_cloud[c];
                                 if (kt > m) m = kt;
+                                if (k_cloud[c] > 0.0f) any_cloud = 1;
                             }
                     const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
                     out->maj[2 * e] = m;
                     out->maj[2 * e + 1] = 1.0f / m;
+                    cloudy[e] = (unsigned char)any_cloud;
                 }
+        int levels = sc->levels;
+        if (levels < 0)
+        {
+            const size_t n = (size_t)nci * ncj * nck;
+            float* trial = (float*)malloc(sizeof(float) * 2 * n);
+            memcpy(trial, out->maj, sizeof(float) * 2 * n);
+            build_regions(nci, ncj, nck, 3, trial, cloudy, out->lvl);
+            size_t merged = 0;
+            for (size_t e = 0; e < n; ++e) merged += out->lvl[e] >= 1;
+            levels = 3 * merged >= n ? 3 : 0;
+            free(trial);
+        }
+        build_regions(nci, ncj, nck, levels, out->maj, cloudy, out->lvl);
+        free(cloudy);
     }
 }
 
@@ -368,6 +439,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
     const float hx = sl->hx, hy = sl->hy, hz = sl->hz;
     const float inv_hx = g >= 0 ? 1.0f / hx : 0.0f, inv_hy = g >= 0 ? 1.0f / hy : 0.0f;
     const float zc0 = g >= 0 ? sl->zface[g] : 0.0f, zc1 = g >= 0 ? sl->zface[g + 1] : 0.0f;
+    const float inv_hz = g >= 0 ? 1.0f / hz : 0.0f;
 
     uint32_t w[4];
     uint32_t nev = 0;
@@ -426,14 +498,20 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         /* ---- traverse one majorant region ---- */
         const int gridded = slab == g;
         float M, invM, tx, ty, tz, fz;
-        const float xlo = (float)ci * hx, xhi = (ci + 1 == nci) ? xs : (float)(ci + 1) * hx;
-        const float ylo = (float)cj * hy, yhi = (cj + 1 == ncj) ? ys : (float)(cj + 1) * hy;
+        /* the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck), clipped at the grid */
+        int L = 0;
+        size_t e = 0;
+        if (gridded) { e = ((size_t)ck * ncj + cj) * nci + ci; L = sl->lvl[e]; }
+        const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
+        const int bx1 = bx0 + (1 << L) < nci ? bx0 + (1 << L) : nci, by1 = by0 + (1 << L) < ncj ? by0 + (1 << L) : ncj,
+                  bz1 = bz0 + (1 << L) < nck ? bz0 + (1 << L) : nck;
+        const float xlo = (float)bx0 * hx, xhi = (bx1 == nci) ? xs : (float)bx1 * hx;
+        const float ylo = (float)by0 * hy, yhi = (by1 == ncj) ? ys : (float)by1 * hy;
         const float fx = iux > 0.0f ? xhi : xlo, fy = iuy > 0.0f ? yhi : ylo;
         if (gridded)
         {
-            const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
             M = sl->maj[2 * e]; invM = sl->maj[2 * e + 1];
-            const float zlo = fmaf((float)ck, hz, zc0), zhi = (ck + 1 == nck) ? zc1 : fmaf((float)(ck + 1), hz, zc0);
+            const float zlo = fmaf((float)bz0, hz, zc0), zhi = (bz1 == nck) ? zc1 : fmaf((float)bz1, hz, zc0);
             fz = iuz > 0.0f ? zhi : zlo;
             tx = face_distance(fx, x, iux); ty = face_distance(fy, y, iuy); tz = face_distance(fz, z, iuz);
         }
@@ -451,6 +529,14 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         const float tt = hit ? t_exit : dn;
         x = fmaf(ux, tt, x); y = fmaf(uy, tt, y); z = fmaf(uz, tt, z);
         if (!gridded) { x = wrap_periodic(x, xs, inv_xs); y = wrap_periodic(y, ys, inv_ys); }
+        if (L > 0)
+        {
+            /* inside a merged region the supervoxel indices follow the position (kept within the region:
+             * a coordinate that sits on one of its faces may round to the neighbour's side) */
+            ci = cell_of(x, inv_hx, nci); ci = ci < bx0 ? bx0 : (ci > bx1 - 1 ? bx1 - 1 : ci);
+            cj = cell_of(y, inv_hy, ncj); cj = cj < by0 ? by0 : (cj > by1 - 1 ? by1 - 1 : cj);
+            ck = (int)((z - zc0) * inv_hz); ck = ck < bz0 ? bz0 : (ck > bz1 - 1 ? bz1 - 1 : ck);
+        }
 
         if (hit)
         {
@@ -460,13 +546,13 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             int leave = 0;                       /* +1: leaves the slab upwards, -1: downwards */
             if (axis == 0)
             {
-                x = fx; ci += iux > 0.0f ? 1 : -1;
+                x = fx; ci = iux > 0.0f ? bx1 : bx0 - 1;
                 if (ci == nci) { ci = 0; x = 0.0f; }
                 if (ci < 0) { ci = nci - 1; x = xs; }
             }
             else if (axis == 1)
             {
-                y = fy; cj += iuy > 0.0f ? 1 : -1;
+                y = fy; cj = iuy > 0.0f ? by1 : by0 - 1;
                 if (cj == ncj) { cj = 0; y = 0.0f; }
                 if (cj < 0) { cj = ncj - 1; y = ys; }
             }
@@ -476,7 +562,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
                 const int up = iuz > 0.0f;
                 if (gridded)
                 {
-                    const int nk = ck + (up ? 1 : -1);
+                    const int nk = up ? bz1 : bz0 - 1;
                     if (nk >= 0 && nk < nck) ck = nk; else leave = up ? 1 : -1;
                 }
                 else

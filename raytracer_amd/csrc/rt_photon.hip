@@ -65,7 +65,10 @@ struct TraceArgs
 {
     const float4* cells;      // {k_tot = gas + cloud, ssa, asy, k_cloud} per cell [k][j][i]: one 16-byte
                               // record, so a collision costs one memory sector however it ends
-    const float2* maj;        // {M, 1/M}: ncoarse supervoxels [ck][cj][ci], then one entry per slab
+    const float2* maj;        // {M, 1/M} of the region a supervoxel belongs to: ncoarse supervoxels
+                              // [ck][cj][ci], then one entry per slab
+    const uint8_t* lvl;       // region level per supervoxel: its region is the aligned cube of 2^lvl
+                              // supervoxels per edge around it (cloud-free supervoxels merged)
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
     uint64_t seed;
@@ -82,7 +85,7 @@ struct TraceArgs
     int gslab;                // index of the slab refined into supervoxels, -1 if none
     int nci, ncj, nck;
     uint32_t ncoarse;
-    float hx, hy, hz, inv_hx, inv_hy, zc0, zc1;
+    float hx, hy, hz, inv_hx, inv_hy, inv_hz, zc0, zc1;
     int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
     int th_launch;            // pool kernel: waiting launches that trigger a launch round
     // stratified launch (launch_log2k >= 0): 2^k consecutive photon IDs per column, columns in
@@ -97,7 +100,8 @@ struct TraceArgs
     // per XCD (kCursorStride words apart), each over its own eighth of the ID range: with the
     // stratified launch an XCD then sweeps its own band of columns and its private L2 keeps that band's
     // cells; a wave whose XCD has run dry takes chunks from the next XCD's range.
-    unsigned long long* cursor;
+    unsigned long long* cursor;               // (the pool kernel reaches the event counters as cursor - kCursorWord:
+                                              // one live pointer less in a loop that is short of SGPRs)
 };
 
 // What only the launch (regeneration) stage and the surface event of the pool kernel need. It lives
@@ -403,15 +407,19 @@ rt_trace_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
+                    // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck)
+                    const int L = gridded ? (int)a.lvl[e] : 0;
+                    const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
+                    const int bx1 = min(bx0 + (1 << L), a.nci), by1 = min(by0 + (1 << L), a.ncj), bz1 = min(bz0 + (1 << L), a.nck);
                     // the face ahead on each axis: index of the cell face, then its coordinate
-                    const int cfx = ci + (iux > 0.0f ? 1 : 0), cfy = cj + (iuy > 0.0f ? 1 : 0);
+                    const int cfx = iux > 0.0f ? bx1 : bx0, cfy = iuy > 0.0f ? by1 : by0;
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
                     const bool up = iuz > 0.0f;
                     float fz;
                     if (gridded)
                     {
-                        const int cfz = ck + (up ? 1 : 0);
+                        const int cfz = up ? bz1 : bz0;
                         fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0);
                     }
                     else
@@ -430,6 +438,14 @@ rt_trace_kernel(const TraceArgs a)
                     const float tt = hit ? t_exit : dn;
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
                     if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
+                    if (L > 0)
+                    {
+                        // inside a merged region the supervoxel indices follow the position (kept within the
+                        // region: a coordinate on one of its faces may round to the neighbour's side)
+                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1);
+                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1);
+                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1);
+                    }
                     inv_m = mm.y;
 
                     if (!hit)
@@ -442,13 +458,13 @@ rt_trace_kernel(const TraceArgs a)
                         int leave = 0;
                         if (axis == 0)
                         {
-                            x = fx; ci += iux > 0.0f ? 1 : -1;
+                            x = fx; ci = iux > 0.0f ? bx1 : bx0 - 1;
                             if (ci == a.nci) { ci = 0; x = 0.0f; }
                             if (ci < 0) { ci = a.nci - 1; x = a.xs; }
                         }
                         else if (axis == 1)
                         {
-                            y = fy; cj += iuy > 0.0f ? 1 : -1;
+                            y = fy; cj = iuy > 0.0f ? by1 : by0 - 1;
                             if (cj == a.ncj) { cj = 0; y = 0.0f; }
                             if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
                         }
@@ -457,7 +473,7 @@ rt_trace_kernel(const TraceArgs a)
                             z = fz;
                             if (gridded)
                             {
-                                const int nk = ck + (up ? 1 : -1);
+                                const int nk = up ? bz1 : bz0 - 1;
                                 if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1;
                             }
                             else
@@ -540,7 +556,7 @@ enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 
 constexpr int kPoolRec = 16;
 constexpr int kPoolBlock = 64;
 
-template <bool FIXED_DOT, bool STATS, int NS>
+template <bool FIXED_DOT, bool STATS, int NS, bool HIER>
 __global__ void __launch_bounds__(kPoolBlock)
 rt_trace_pool_kernel(const TraceArgs a)
 {
@@ -557,10 +573,8 @@ rt_trace_pool_kernel(const TraceArgs a)
     // photon IDs of this wave: wave_left IDs from wave_next on, a chunk taken from the device-wide cursor
     uint64_t wave_next = 0;
     uint32_t wave_left = 0;
-    bool exhausted = false;
     // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on; ranges of XCDs found empty so far
-    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kXcds - 1);
-    uint32_t ranges_dry = 0;
+    uint32_t ranges_dry = 0;              // == kXcds: no photon ID is left anywhere
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
 
@@ -746,7 +760,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                             // absorption, raytracer_kernels.cu:551-566
                             if (STATS) ++ev_abs;
                             const bool diffuse = (cks >> 24) & 1u;
-                            tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncell : 0u) + cell]);
+                            tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncol * (uint32_t)a.ktot : 0u) + cell]);
                             ns = PS_LAUNCH;
                         }
                     }
@@ -766,16 +780,17 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
             }
         }
-        else if (cls == 3u)
+        else if (__builtin_expect(cls == 3u, 0))
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
             const LaunchBlock* const lb = a.launch;
-            while (wave_left == 0u && !exhausted)
+            while (__builtin_expect(wave_left == 0u && ranges_dry < (uint32_t)kXcds, 0))
             {
                 // next chunk of IDs from this XCD's range (or the next range that has any left): one
                 // returning atomic per chunk, broadcast from lane 0
                 const uint32_t chunk = lb->chunk;
                 const uint64_t total = lb->total, sub = lb->sub_size;
+                const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
                 const uint32_t x = (xcc + ranges_dry) & (kXcds - 1);
                 const uint64_t sub_lo = (uint64_t)x * sub;
                 const uint64_t sub_hi = sub_lo + sub < total ? sub_lo + sub : total;
@@ -788,8 +803,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 c0 = (((unsigned long long)c0_hi << 32) | c0_lo) + sub_lo;
                 if (sub_lo >= total || c0 >= sub_hi)
                 {
-                    if (++ranges_dry == (uint32_t)kXcds)
-                        exhausted = true;
+                    ++ranges_dry;
                 }
                 else
                 {
@@ -798,7 +812,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
             }
             const bool go = active && (uint32_t)lane < wave_left;
-            if (active && !exhausted)
+            if (active && ranges_dry < (uint32_t)kXcds)
                 ns = PS_LAUNCH;          // no ID left in this chunk: wait for the next one
             uint32_t toa_col = 0xffffffffu;
             if (go)
@@ -876,9 +890,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const bool diffuse = (cks >> 24) & 1u;
                 ns = PS_TRAVERSE;
                 uint32_t w11 = RW(11);
-                if (nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y))
+                if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0))
                 {
-                    tally_add(&a.events[RT_EV_ABORT]);
+                    tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]);
                     ns = PS_LAUNCH;
                 }
                 else
@@ -889,14 +903,23 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
-                    const int cfx = ci + (g2.x > 0.0f ? 1 : 0), cfy = cj + (g2.y > 0.0f ? 1 : 0);
+                    // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck); the
+                    // variant without merged regions (HIER = false) skips the level fetch and the cube arithmetic
+                    const int L = HIER && gridded ? (int)a.lvl[e] : 0;
+                    int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1;
+                    if (HIER)
+                    {
+                        bx0 = (ci >> L) << L; by0 = (cj >> L) << L; bz0 = (ck >> L) << L;
+                        bx1 = min(bx0 + (1 << L), a.nci); by1 = min(by0 + (1 << L), a.ncj); bz1 = min(bz0 + (1 << L), a.nck);
+                    }
+                    const int cfx = g2.x > 0.0f ? bx1 : bx0, cfy = g2.y > 0.0f ? by1 : by0;
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
                     const bool up = g2.z > 0.0f;
                     float fz;
                     if (gridded)
                     {
-                        const int cfz = ck + (up ? 1 : 0);
+                        const int cfz = up ? bz1 : bz0;
                         fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0);
                     }
                     else
@@ -915,6 +938,14 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const float tt = hit ? t_exit : dn;
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
                     if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
+                    if (HIER && L > 0)
+                    {
+                        // inside a merged region the supervoxel indices follow the position (kept within the
+                        // region: a coordinate on one of its faces may round to the neighbour's side)
+                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1);
+                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1);
+                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1);
+                    }
                     w11 = __float_as_uint(mm.y);
 
                     if (!hit)
@@ -927,13 +958,13 @@ rt_trace_pool_kernel(const TraceArgs a)
                         int leave = 0;
                         if (axis == 0)
                         {
-                            x = fx; ci += g2.x > 0.0f ? 1 : -1;
+                            x = fx; ci = g2.x > 0.0f ? bx1 : bx0 - 1;
                             if (ci == a.nci) { ci = 0; x = 0.0f; }
                             if (ci < 0) { ci = a.nci - 1; x = a.xs; }
                         }
                         else if (axis == 1)
                         {
-                            y = fy; cj += g2.y > 0.0f ? 1 : -1;
+                            y = fy; cj = g2.y > 0.0f ? by1 : by0 - 1;
                             if (cj == a.ncj) { cj = 0; y = 0.0f; }
                             if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
                         }
@@ -942,13 +973,13 @@ rt_trace_pool_kernel(const TraceArgs a)
                             z = fz;
                             if (gridded)
                             {
-                                const int nk = ck + (up ? 1 : -1);
+                                const int nk = up ? bz1 : bz0 - 1;
                                 if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1;
                             }
                             else
                                 leave = up ? 1 : -1;
                         }
-                        if (leave != 0)
+                        if (__builtin_expect(leave != 0, 0))
                         {
                             const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
                             const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
@@ -1006,14 +1037,14 @@ rt_trace_pool_kernel(const TraceArgs a)
 #pragma unroll
         for (int e = 0; e < 9; ++e)
             if (ev[e])
-                __hip_atomic_fetch_add(&a.events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&(a.cursor - kCursorWord)[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0)
         {
             const uint32_t sch[6] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s};
 #pragma unroll
             for (int e = 0; e < 6; ++e)
-                __hip_atomic_fetch_add(&a.events[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&(a.cursor - kCursorWord)[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1023,7 +1054,7 @@ rt_trace_pool_kernel(const TraceArgs a)
 // Majorant grid of the cloud slab: one wave per supervoxel, max of k_tot over its cells, stored
 // as {M, 1/M}. (Generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels.)
 __global__ void __launch_bounds__(64)
-rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj,
+rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, uint8_t* __restrict__ cloudy,
                    int itot, int jtot, uint32_t ncol, int k_lo, int k_end,
                    int sx, int sy, int sz, int nci, int ncj)
 {
@@ -1033,12 +1064,15 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj,
     const int ni = min(sx, itot - i0), nj = min(sy, jtot - j0), nk = min(sz, k_end - k0);
     const int n = ni * nj * nk;
     float m = 0.0f;
+    bool cloud = false;
     for (int t = threadIdx.x; t < n; t += 64)
     {
         const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
-        const float v = cells[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol].x;
-        m = v > m ? v : m;
+        const float4 cr = cells[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol];
+        m = cr.x > m ? cr.x : m;
+        cloud |= cr.w > 0.0f;
     }
+    const bool any_cloud = __ballot(cloud) != 0ull;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
     {
@@ -1046,7 +1080,10 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj,
         m = o > m ? o : m;
     }
     if (threadIdx.x == 0)
+    {
         maj[e] = make_float2(m, 1.0f / m);
+        cloudy[e] = any_cloud ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1147,6 +1184,9 @@ struct rt_context
 
     float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
+    uint8_t* d_lvl = nullptr;         // region level per supervoxel (also the scratch of the cloud flags)
+    int levels = -1;                  // largest region: cubes of 2^levels supervoxels per edge; < 0 = automatic
+    bool hier = false;                // any region larger than a supervoxel (selects the kernel variant)
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
     int sgx = 8, sgy = 8, sgz = 4;    // supervoxel size in cells (0 = no grid, slabs only)
@@ -1213,6 +1253,45 @@ void build_slabs(rt_context* c)
 
 // (Re)builds the majorant table on the device: supervoxels of the cloud slab (if the grid is
 // enabled and a cloud slab exists), followed by one {M, 1/M} entry per slab.
+// Region hierarchy over the supervoxel grid (host side of the pre-pass): a supervoxel without any cloud
+// cell takes the largest level L <= max_level for which the whole aligned cube of 2^L supervoxels per
+// edge around it (clipped at the grid) is cloud-free; the members of such a cube share one region whose
+// majorant is the maximum over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out.
+void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>& maj,
+                   const std::vector<uint8_t>& cloudy, std::vector<uint8_t>& lvl)
+{
+    std::fill(lvl.begin(), lvl.end(), (uint8_t)0);
+    for (int L = 1; L <= max_level; ++L)
+    {
+        const int sz = 1 << L;
+        for (int bk = 0; bk < nck; bk += sz)
+            for (int bj = 0; bj < ncj; bj += sz)
+                for (int bi = 0; bi < nci; bi += sz)
+                {
+                    const int k1 = std::min(bk + sz, nck), j1 = std::min(bj + sz, ncj), i1 = std::min(bi + sz, nci);
+                    bool clear = true;
+                    float m = 0.0f;
+                    for (int k = bk; k < k1 && clear; ++k)
+                        for (int j = bj; j < j1 && clear; ++j)
+                            for (int i = bi; i < i1; ++i)
+                            {
+                                const size_t e = ((size_t)k * ncj + j) * nci + i;
+                                if (cloudy[e]) { clear = false; break; }
+                                if (maj[e].x > m) m = maj[e].x;
+                            }
+                    if (!clear) continue;
+                    for (int k = bk; k < k1; ++k)
+                        for (int j = bj; j < j1; ++j)
+                            for (int i = bi; i < i1; ++i)
+                            {
+                                const size_t e = ((size_t)k * ncj + j) * nci + i;
+                                lvl[e] = (uint8_t)L;
+                                maj[e] = make_float2(m, 1.0f / m);
+                            }
+                }
+    }
+}
+
 int build_majorants(rt_context* c)
 {
     rt_slab_info& s = c->slabs;
@@ -1234,19 +1313,45 @@ int build_majorants(rt_context* c)
         if (c->d_maj) RT_HIP(hipFree(c->d_maj));
         c->d_maj = nullptr;
         RT_HIP(hipMalloc(&c->d_maj, sizeof(float2) * (ncoarse + 3)));
+        if (c->d_lvl) RT_HIP(hipFree(c->d_lvl));
+        c->d_lvl = nullptr;
+        RT_HIP(hipMalloc(&c->d_lvl, ncoarse + 4));
         c->maj_capacity = ncoarse + 3;
     }
     if (ncoarse)
     {
         hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)ncoarse), dim3(64), 0, c->stream,
-                           c->d_cells, c->d_maj, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
+                           c->d_cells, c->d_maj, c->d_lvl, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
                            c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
         RT_HIP(hipGetLastError());
+        // merge cloud-free supervoxels into regions (small: one entry per supervoxel), on the host
+        std::vector<float2> h_maj(ncoarse);
+        std::vector<uint8_t> h_cloudy(ncoarse), h_lvl(ncoarse);
+        RT_HIP(hipMemcpyAsync(h_maj.data(), c->d_maj, sizeof(float2) * ncoarse, hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(hipMemcpyAsync(h_cloudy.data(), c->d_lvl, ncoarse, hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));
+        int levels = c->levels;
+        if (levels < 0)
+        {
+            // automatic: merging pays in sparse cloud fields and costs a little in dense ones
+            std::vector<float2> trial(h_maj);
+            build_regions(s.nci, s.ncj, s.nck, 3, trial, h_cloudy, h_lvl);
+            size_t merged = 0;
+            for (size_t e = 0; e < ncoarse; ++e) merged += h_lvl[e] >= 1;
+            levels = 3 * merged >= ncoarse ? 3 : 0;
+        }
+        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_cloudy, h_lvl);
+        c->hier = false;
+        for (size_t e = 0; e < ncoarse && !c->hier; ++e) c->hier = h_lvl[e] > 0;
+        RT_HIP(hipMemcpyAsync(c->d_maj, h_maj.data(), sizeof(float2) * ncoarse, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(hipMemcpyAsync(c->d_lvl, h_lvl.data(), ncoarse, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(hipStreamSynchronize(c->stream));
     }
     float2 slab_m[3];
     for (int i = 0; i < 3; ++i) slab_m[i] = make_float2(s.kmaj[i], c->inv_kmaj[i]);
     RT_HIP(hipMemcpyAsync(c->d_maj + ncoarse, slab_m, sizeof(slab_m), hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
+    if (!ncoarse) c->hier = false;
     c->ncoarse = ncoarse;
     c->maj_dirty = false;
     return RT_OK;
@@ -1343,6 +1448,7 @@ int rt_destroy(rt_context* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_maj) (void)hipFree(c->d_maj);
+    if (c->d_lvl) (void)hipFree(c->d_lvl);
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
     if (c->d_launch) (void)hipFree(c->d_launch);
@@ -1415,6 +1521,12 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
         c->launch_log2k = (int)value;
     }
+    else if (!strcmp(name, "levels"))
+    {
+        if (value < -1 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,6]", value);
+        c->levels = (int)value;
+        c->maj_dirty = true;
+    }
     else if (!strcmp(name, "chunk"))
     {
         if (value < 64 || value > (1 << 20) || (value & (value - 1)))
@@ -1485,11 +1597,13 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.nslab = c->slabs.nslab;
     for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
     a.maj = c->d_maj;
+    a.lvl = c->d_lvl;
     a.gslab = c->slabs.gslab;
     a.nci = c->slabs.nci; a.ncj = c->slabs.ncj; a.nck = c->slabs.nck;
     a.ncoarse = (uint32_t)c->ncoarse;
     a.hx = c->slabs.hx; a.hy = c->slabs.hy; a.hz = c->slabs.hz;
     a.inv_hx = a.gslab >= 0 ? 1.0f / a.hx : 0.0f; a.inv_hy = a.gslab >= 0 ? 1.0f / a.hy : 0.0f;
+    a.inv_hz = a.gslab >= 0 ? 1.0f / a.hz : 0.0f;
     a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
     a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
     a.th_launch = c->th_launch;
@@ -1542,12 +1656,16 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         uint64_t pblocks = (count + chunk - 1) / chunk;
         if (pblocks > pcap) pblocks = pcap;
         const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
+#define RT_LAUNCH_POOL_H(NS, H)                                                                                    \
+        do {                                                                                                       \
+            if (c->fixed_dot) { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<true, true, NS, H>), grid, pblock, 0, c->stream, a);   \
+                                else hipLaunchKernelGGL((rt_trace_pool_kernel<true, false, NS, H>), grid, pblock, 0, c->stream, a); }        \
+            else { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<false, true, NS, H>), grid, pblock, 0, c->stream, a);              \
+                   else hipLaunchKernelGGL((rt_trace_pool_kernel<false, false, NS, H>), grid, pblock, 0, c->stream, a); }                    \
+        } while (0)
 #define RT_LAUNCH_POOL(NS)                                                                                         \
         do {                                                                                                       \
-            if (c->fixed_dot) { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<true, true, NS>), grid, pblock, 0, c->stream, a);   \
-                                else hipLaunchKernelGGL((rt_trace_pool_kernel<true, false, NS>), grid, pblock, 0, c->stream, a); }        \
-            else { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<false, true, NS>), grid, pblock, 0, c->stream, a);              \
-                   else hipLaunchKernelGGL((rt_trace_pool_kernel<false, false, NS>), grid, pblock, 0, c->stream, a); }                    \
+            if (c->hier) RT_LAUNCH_POOL_H(NS, true); else RT_LAUNCH_POOL_H(NS, false);                                 \
         } while (0)
         switch (ns)
         {
@@ -1559,6 +1677,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
             default: RT_LAUNCH_POOL(256); break;
         }
 #undef RT_LAUNCH_POOL
+#undef RT_LAUNCH_POOL_H
     }
     else
     {
@@ -1693,6 +1812,22 @@ int rt_get_majorants(rt_context* c, float* out_pairs, size_t n_pairs)
     if (n_pairs != c->ncoarse)
         return fail(RT_ERR_ARG, "rt_get_majorants: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n_pairs);
     if (n_pairs) RT_HIP(hipMemcpy(out_pairs, c->d_maj, sizeof(float2) * n_pairs, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_region_levels(rt_context* c, uint8_t* out, size_t n)
+{
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_region_levels: null argument");
+    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_region_levels: call rt_upload_optics first");
+    RT_HIP(hipSetDevice(c->device));
+    if (c->maj_dirty)
+    {
+        const int rc = build_majorants(c);
+        if (rc != RT_OK) return rc;
+    }
+    if (n != c->ncoarse)
+        return fail(RT_ERR_ARG, "rt_get_region_levels: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n);
+    if (n) RT_HIP(hipMemcpy(out, c->d_lvl, n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -66,6 +66,7 @@ def load_library():
         "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
         "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
+        "rt_get_region_levels": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_size_t]),
         "rt_get_events": (C.c_int, [vp, u64p]),
         "rt_get_sched_stats": (C.c_int, [vp, u64p]),
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -205,6 +206,17 @@ class PhotonTracer:
             return None
         out = np.zeros((s.nck, s.ncj, s.nci, 2), dtype=np.float32)
         _check(self.lib.rt_get_majorants(self._h, _f32p(out), n))
+        return out
+
+    def region_levels(self):
+        """Region level of every supervoxel, uint8 [nck, ncj, nci] (or None): cloud-free supervoxels are merged
+        into aligned cubes of 2^level supervoxels per edge; majorants() holds the region's pair."""
+        s = self.slabs()
+        n = s.nci * s.ncj * s.nck
+        if n == 0:
+            return None
+        out = np.zeros((s.nck, s.ncj, s.nci), dtype=np.uint8)
+        _check(self.lib.rt_get_region_levels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n))
         return out
 
     def set_supergrid(self, sx, sy, sz):

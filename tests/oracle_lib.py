@@ -27,14 +27,15 @@ class OracleScene(C.Structure):
                 ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
                 ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
                 ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int),
-                ("launch_log2k", C.c_int), ("planar", C.c_int)]
+                ("launch_log2k", C.c_int), ("planar", C.c_int), ("levels", C.c_int)]
 
 
 class OracleSlabs(C.Structure):
     _fields_ = [("nslab", C.c_int), ("zface", C.c_float * 4), ("kmaj", C.c_float * 3),
                 ("inv_kmaj", C.c_float * 3), ("k_lo", C.c_int), ("k_hi", C.c_int),
                 ("sun", C.c_float * 3), ("gslab", C.c_int), ("nci", C.c_int), ("ncj", C.c_int), ("nck", C.c_int),
-                ("hx", C.c_float), ("hy", C.c_float), ("hz", C.c_float), ("maj", C.POINTER(C.c_float))]
+                ("hx", C.c_float), ("hy", C.c_float), ("hz", C.c_float), ("maj", C.POINTER(C.c_float)),
+                ("lvl", C.POINTER(C.c_ubyte))]
 
 
 _lib = None
@@ -93,20 +94,24 @@ def new_tallies(scene):
 DEFAULT_SUPERGRID = (8, 8, 4)     # must equal the product's default (rt_set_option "supergrid_*")
 
 
-def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False) -> OracleScene:
+DEFAULT_LEVELS = -1     # the library's default of option "levels": automatic
+
+
+def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False,
+                 levels=DEFAULT_LEVELS) -> OracleScene:
     f = np.float32
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
-                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar))
+                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar), int(levels))
 
 
 def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False,
-                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False):
+                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False, levels=DEFAULT_LEVELS):
     """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
     t = tallies if tallies is not None else new_tallies(scene)
     ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
-    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar)
+    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar, levels)
     fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
                                    seed, pid_begin, count, nthreads,
@@ -116,14 +121,16 @@ def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed
     return t, dict(zip(EVENT_NAMES, (int(v) for v in ev)))
 
 
-def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID) -> OracleSlabs:
-    """Slabs + majorant grid; `.maj_array` holds a copy of the {M, 1/M} pairs [nck, ncj, nci, 2]."""
-    sc = oracle_scene(scene, supergrid=supergrid)
+def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID, levels=DEFAULT_LEVELS) -> OracleSlabs:
+    """Slabs + majorant grid; `.maj_array` holds a copy of the {M, 1/M} pairs [nck, ncj, nci, 2] and
+    `.lvl_array` the region levels [nck, ncj, nci]."""
+    sc = oracle_scene(scene, supergrid=supergrid, levels=levels)
     sl = OracleSlabs()
     kg, kc, _, asy = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     lib().oracle_build_slabs(C.byref(sc), _p(kg, C.c_float), _p(kc, C.c_float), _p(asy, C.c_float), C.byref(sl))
     n = sl.nci * sl.ncj * sl.nck
     sl.maj_array = np.ctypeslib.as_array(sl.maj, shape=(2 * n,)).copy().reshape(sl.nck, sl.ncj, sl.nci, 2) if n else None
+    sl.lvl_array = np.ctypeslib.as_array(sl.lvl, shape=(n,)).copy().reshape(sl.nck, sl.ncj, sl.nci) if n else None
     lib().oracle_free_slabs(C.byref(sl))
     return sl
 

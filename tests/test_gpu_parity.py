@@ -104,9 +104,10 @@ def _check_structures(tr, scene, supergrid):
     assert (sl.hx, sl.hy, sl.hz) == (osl.hx, osl.hy, osl.hz)
     maj = tr.majorants()
     if osl.maj_array is None:
-        assert maj is None
+        assert maj is None and tr.region_levels() is None
     else:
         assert np.array_equal(maj.view(np.uint32), osl.maj_array.view(np.uint32))
+        assert np.array_equal(tr.region_levels(), osl.lvl_array)
 
 
 @pytest.mark.parametrize("scene_name,n,supergrid", [
@@ -195,6 +196,27 @@ def test_planar_mode_bit_identical_to_oracle(rt, n, supergrid):
     with pytest.raises(rt.RtError, match="planar"):
         lane.trace(1, 0, 10)
     lane.close()
+
+
+@pytest.mark.parametrize("pool", [0, 128])
+@pytest.mark.parametrize("scene_name,n,supergrid,levels", [
+    ("block_cloud", 1 << 18, (8, 8, 4), 0), ("block_cloud", 1 << 18, (8, 8, 4), 1), ("block_cloud", 1 << 18, (8, 8, 4), 3),
+    ("block_cloud", 1 << 17, (4, 4, 2), 4), ("cumulus_small", 1 << 17, (8, 8, 4), 3), ("cumulus_small", 1 << 17, (2, 2, 2), 2),
+    ("tiny", 1 << 16, (1, 1, 1), 3), ("tiny", 1 << 16, (5, 3, 2), 1), ("cloud_to_top", 1 << 15, (4, 4, 1), 2)])
+def test_region_hierarchy_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid, levels):
+    """Cloud-free supervoxels merged into cubes of up to 2^levels per edge (option "levels"): fewer, larger
+    majorant regions; the levels, the region majorants and every tally must equal the oracle's."""
+    scene = SCENES[scene_name](rt.scenes)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels)
+    tr.set_supergrid(*supergrid)
+    osl = O.oracle_slabs(scene, supergrid=supergrid, levels=levels)
+    assert np.array_equal(tr.region_levels(), osl.lvl_array) and int(osl.lvl_array.max()) <= levels
+    assert np.array_equal(tr.majorants().view(np.uint32), osl.maj_array.view(np.uint32))
+    tr.trace(99, 123_456_789_000, n); tr.synchronize()
+    want, ev = O.photon_oracle(scene, 99, 123_456_789_000, n, supergrid=supergrid, levels=levels)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev
+    tr.close()
 
 
 def test_frozen_golden_vector(rt):

@@ -22,7 +22,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=128, chunk=256, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=128, chunk=256, levels=2, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
 for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
     if "=" in kv:
         base[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -43,6 +43,9 @@ elif what == "pool2":
 elif what == "launch2":
     for lk in (-1, 3, 5, 6, 7, 8):
         o = dict(base, pool=128, launch_log2k=lk); res.append((run(o, 3), lk))
+elif what == "levels":
+    for lv in (0, 1, 2, 3, 4):
+        o = dict(base, pool=128, levels=lv); res.append((run(o, 3), lv))
 elif what == "one":
     o = dict(base, pool=128); res.append((run(o, 5), "default"))
 elif what == "chunk":
