@@ -729,7 +729,12 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                     cell = w11;          // surface column stored by the traverse stage
                 const float kt = cr.x;
-                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, key0, key1);
+                // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
+                // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
+                // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
+                uint32_t rk0 = key0, rk1 = key1;
+                asm volatile("" : "+s"(rk0), "+s"(rk1));
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
                 ++nev;
                 float tau_new = free_path_tau(u01(w.y));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
