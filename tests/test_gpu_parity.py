@@ -376,13 +376,16 @@ def test_c3_cumulus_statistics_against_reference_restatement(rt):
 @pytest.mark.parametrize("pool", [0, 128])
 @pytest.mark.parametrize("scene_name,n,log2k", [("tiny", 192 * 32 * 3 + 777, 5), ("tiny", 50000, 0), ("tiny", 50000, 9),
                                                 ("few_columns", 40000, 3), ("few_columns", 40000, 0),
+                                                ("six_columns", 30000, 0), ("six_columns", 30000, 2),
                                                 ("block_cloud", 1 << 18, 5), ("cumulus_small", 1 << 17, 4)])
 def test_stratified_launch_bit_identical_to_oracle(rt, pool, scene_name, n, log2k):
     """Stratified launch (2^k consecutive photon IDs per column, rotated passes): both kernels
     against the oracle, including grids with < 128 columns (exact-division path) and ID ranges
     that start in the middle of a pass."""
     scene = rt.scenes.cumulus(8, 6, 10, 100.0, 80.0, 60.0, n_clouds=2, seed=2, z_base=180.0, z_top=480.0) \
-        if scene_name == "few_columns" else SCENES[scene_name](rt.scenes)
+        if scene_name == "few_columns" else (None if scene_name == "six_columns" else SCENES[scene_name](rt.scenes))
+    if scene_name == "six_columns":     # passes of 6 IDs: the 64 lanes of one launch round span many passes
+        scene = rt.scenes.cumulus(3, 2, 8, 100.0, 80.0, 60.0, n_clouds=1, seed=4, z_base=120.0, z_top=360.0)
     begin = 123_456_789_012
     tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, launch_log2k=log2k)
     tr.trace(99, begin, n); tr.synchronize()
