@@ -121,10 +121,11 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    +-acos(mu) in that plane, the surface reflects to (+-mu, 0, sqrt(1-mu^2))). With
  *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
- *                    (default 8, 8, 4; 0 = slab majorants only, the reference's scheme)
- *   "levels"         cloud-free supervoxels are merged into aligned cubes of up to 2^levels supervoxels per
- *                    edge, each crossed as one majorant region (0 = one region per supervoxel; default -1 =
- *                    automatic: 3 if at least a third of the supervoxels then lie in merged regions, else 0)
+ *                    (default 3, 3, 2; 0 = slab majorants only, the reference's scheme)
+ *   "levels"         supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
+ *                    each crossed as one majorant region, wherever (majorant - mean extinction) * edge length
+ *                    <= "merge_tau_milli" / 1000 — the optical depth of null collisions a crossing photon would
+ *                    meet (defaults 5 and 2000; levels = 0: one region per supervoxel)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change)

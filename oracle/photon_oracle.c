@@ -212,10 +212,11 @@ typedef struct
                    a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
                    surface reflects to (+-mu, 0, sqrt(1-mu^2)) (raytracer.cpp:280-282); the signs are the top
                    bit of the draw that is the azimuth in 3D. Meant for jtot = 1 and azimuth = 0. */
-    int levels; /* cloud-free supervoxels are merged into aligned cubes of up to 2^levels supervoxels per
-                   edge, each crossed as ONE majorant region (0 = every supervoxel is its own region; < 0 =
-                   automatic: 3 if at least a third of the supervoxels then lie in merged regions, else 0 —
-                   merging pays in sparse cloud fields and costs a little in dense ones) */
+    int levels; /* supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
+                   each crossed as ONE majorant region, wherever that wastes little (0 = no merging) */
+    float merge_tau; /* a cube is merged when (majorant - mean extinction) * edge length <= merge_tau: the
+                        optical depth of null collisions a photon crossing it would meet. Clear air merges
+                        at any size, homogeneous cloud too; cloud edges keep their fine supervoxels. */
 } oracle_scene_t;
 
 /* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
@@ -241,12 +242,14 @@ typedef struct
 
 void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->lvl); s->lvl = NULL; }
 
-/* Region hierarchy over the supervoxel grid. A supervoxel without any cloud cell takes the largest
- * level L <= max_level for which the whole aligned cube of 2^L supervoxels per edge around it (clipped
- * at the grid) is cloud-free; all members of such a cube then share one region whose majorant is the
- * maximum over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out. */
-static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, const unsigned char* cloudy,
-                          unsigned char* lvl)
+/* Region hierarchy over the supervoxel grid, built bottom-up: the aligned cube of 2^L supervoxels per edge
+ * (clipped at the grid) becomes one region if all its members are regions of level L-1 and
+ * (M - mean k_tot) * (2^L * edge) <= tau, with M the maximum and mean the volume mean of the extinction
+ * over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out. ksum/kcnt: sum (double, cells in
+ * k, j, i order) and number of cells per supervoxel. All arithmetic of the criterion is double, in a
+ * fixed order, so that the library's copy of this routine decides identically. */
+static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, const double* ksum, const int* kcnt,
+                          float edge, float tau, unsigned char* lvl)
 {
     const size_t n = (size_t)nci * ncj * nck;
     memset(lvl, 0, n);
@@ -259,19 +262,22 @@ static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, 
                 {
                     const int k1 = bk + sz < nck ? bk + sz : nck, j1 = bj + sz < ncj ? bj + sz : ncj,
                               i1 = bi + sz < nci ? bi + sz : nci;
-                    int clear = 1;
+                    int ok = 1;
                     float m = 0.0f;
-                    for (int k = bk; k < k1 && clear; ++k)
-                        for (int j = bj; j < j1 && clear; ++j)
+                    double sum = 0.0;
+                    long long cnt = 0;
+                    for (int k = bk; k < k1 && ok; ++k)
+                        for (int j = bj; j < j1 && ok; ++j)
                             for (int i = bi; i < i1; ++i)
                             {
                                 const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                if (cloudy[e]) { clear = 0; break; }
+                                if (lvl[e] != L - 1) { ok = 0; break; }
                                 if (maj[2 * e] > m) m = maj[2 * e];
+                                sum += ksum[e];
+                                cnt += kcnt[e];
                             }
-                    if (!clear) continue;
-                    /* members of a clear cube already carry the maximum over their (clear) sub-cubes, so
-                     * m is the maximum of the original values over the whole cube */
+                    if (!ok) continue;
+                    if (((double)m - sum / (double)cnt) * (double)edge * (double)sz > (double)tau) continue;
                     for (int k = bk; k < k1; ++k)
                         for (int j = bj; j < j1; ++j)
                             for (int i = bi; i < i1; ++i)
@@ -348,13 +354,15 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         out->hx = (float)sc->sx * sc->dx; out->hy = (float)sc->sy * sc->dy; out->hz = (float)sc->sz * sc->dz;
         out->maj = (float*)malloc(sizeof(float) * 2 * (size_t)nci * ncj * nck);
         out->lvl = (unsigned char*)malloc((size_t)nci * ncj * nck);
-        unsigned char* cloudy = (unsigned char*)malloc((size_t)nci * ncj * nck);
+        double* ksum = (double*)malloc(sizeof(double) * (size_t)nci * ncj * nck);
+        int* kcnt = (int*)malloc(sizeof(int) * (size_t)nci * ncj * nck);
         for (int ck = 0; ck < nck; ++ck)
             for (int cj = 0; cj < ncj; ++cj)
                 for (int ci = 0; ci < nci; ++ci)
                 {
                     float m = 0.0f;
-                    int any_cloud = 0;
+                    double sum = 0.0;
+                    int cnt = 0;
                     const int k1 = k_lo + (ck + 1) * sc->sz < k_hi + 1 ? k_lo + (ck + 1) * sc->sz : k_hi + 1;
                     const int j1 = (cj + 1) * sc->sy < sc->jtot ? (cj + 1) * sc->sy : sc->jtot;
                     const int i1 = (ci + 1) * sc->sx < sc->itot ? (ci + 1) * sc->sx : sc->itot;
@@ -365,27 +373,18 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
                                 const size_t c = (size_t)i + (size_t)j * sc->itot + (size_t)k * nlev;
                                 const float kt = k_gas[c] + k_cloud[c];
                                 if (kt > m) m = kt;
-                                if (k_cloud[c] > 0.0f) any_cloud = 1;
+                                sum += (double)kt;
+                                ++cnt;
                             }
                     const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
                     out->maj[2 * e] = m;
                     out->maj[2 * e + 1] = 1.0f / m;
-                    cloudy[e] = (unsigned char)any_cloud;
+                    ksum[e] = sum;
+                    kcnt[e] = cnt;
                 }
-        int levels = sc->levels;
-        if (levels < 0)
-        {
-            const size_t n = (size_t)nci * ncj * nck;
-            float* trial = (float*)malloc(sizeof(float) * 2 * n);
-            memcpy(trial, out->maj, sizeof(float) * 2 * n);
-            build_regions(nci, ncj, nck, 3, trial, cloudy, out->lvl);
-            size_t merged = 0;
-            for (size_t e = 0; e < n; ++e) merged += out->lvl[e] >= 1;
-            levels = 3 * merged >= n ? 3 : 0;
-            free(trial);
-        }
-        build_regions(nci, ncj, nck, levels, out->maj, cloudy, out->lvl);
-        free(cloudy);
+        build_regions(nci, ncj, nck, sc->levels > 0 ? sc->levels : 0, out->maj, ksum, kcnt, out->hx, sc->merge_tau,
+                      out->lvl);
+        free(ksum); free(kcnt);
     }
 }
 

@@ -1056,39 +1056,39 @@ rt_trace_pool_kernel(const TraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Majorant grid of the cloud slab: one wave per supervoxel, max of k_tot over its cells, stored
-// as {M, 1/M}. (Generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels.)
+// Majorant grid of the cloud slab: per supervoxel the max of k_tot over its cells, stored as {M, 1/M}
+// (generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels), and the sum and
+// number of its cells for the merge criterion.
 __global__ void __launch_bounds__(64)
-rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, uint8_t* __restrict__ cloudy,
+rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, double* __restrict__ ksum,
+                   int* __restrict__ kcnt, uint32_t ncoarse,
                    int itot, int jtot, uint32_t ncol, int k_lo, int k_end,
                    int sx, int sy, int sz, int nci, int ncj)
 {
-    const uint32_t e = blockIdx.x;
+    // One THREAD per supervoxel, cells visited in (k, j, i) order: the double-precision sum of k_tot feeds the
+    // merge criterion of build_regions, which must decide exactly as the oracle's does, so its rounding
+    // must not depend on a reduction tree. Runs once per scene.
+    const uint32_t e = blockIdx.x * 64u + threadIdx.x;
+    if (e >= ncoarse)
+        return;
     const int ci = e % nci, cj = (e / nci) % ncj, ck = e / (nci * ncj);
     const int i0 = ci * sx, j0 = cj * sy, k0 = k_lo + ck * sz;
-    const int ni = min(sx, itot - i0), nj = min(sy, jtot - j0), nk = min(sz, k_end - k0);
-    const int n = ni * nj * nk;
+    const int i1 = min(i0 + sx, itot), j1 = min(j0 + sy, jtot), k1 = min(k0 + sz, k_end);
     float m = 0.0f;
-    bool cloud = false;
-    for (int t = threadIdx.x; t < n; t += 64)
-    {
-        const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
-        const float4 cr = cells[(size_t)(i0 + i) + (size_t)(j0 + j) * itot + (size_t)(k0 + k) * ncol];
-        m = cr.x > m ? cr.x : m;
-        cloud |= cr.w > 0.0f;
-    }
-    const bool any_cloud = __ballot(cloud) != 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-    {
-        const float o = __shfl_xor(m, off, 64);
-        m = o > m ? o : m;
-    }
-    if (threadIdx.x == 0)
-    {
-        maj[e] = make_float2(m, 1.0f / m);
-        cloudy[e] = any_cloud ? 1 : 0;
-    }
+    double sum = 0.0;
+    int cnt = 0;
+    for (int k = k0; k < k1; ++k)
+        for (int j = j0; j < j1; ++j)
+            for (int i = i0; i < i1; ++i)
+            {
+                const float v = cells[(size_t)i + (size_t)j * itot + (size_t)k * ncol].x;
+                m = v > m ? v : m;
+                sum += (double)v;
+                ++cnt;
+            }
+    maj[e] = make_float2(m, 1.0f / m);
+    ksum[e] = sum;
+    kcnt[e] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1190,11 +1190,13 @@ struct rt_context
     float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
     uint8_t* d_lvl = nullptr;         // region level per supervoxel (also the scratch of the cloud flags)
-    int levels = -1;                  // largest region: cubes of 2^levels supervoxels per edge; < 0 = automatic
+    int levels = 5;                   // largest region: cubes of 2^levels supervoxels per edge (0 = no merging)
+    int merge_tau_milli = 2000;       // merge criterion: (M - mean k_tot) * edge <= merge_tau_milli / 1000
     bool hier = false;                // any region larger than a supervoxel (selects the kernel variant)
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
-    int sgx = 8, sgy = 8, sgz = 4;    // supervoxel size in cells (0 = no grid, slabs only)
+    int sgx = 3, sgy = 3, sgz = 2;    // supervoxel size in cells (0 = no grid, slabs only): fine, because
+                                      // build_regions merges them wherever the field is homogeneous
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
@@ -1258,12 +1260,14 @@ void build_slabs(rt_context* c)
 
 // (Re)builds the majorant table on the device: supervoxels of the cloud slab (if the grid is
 // enabled and a cloud slab exists), followed by one {M, 1/M} entry per slab.
-// Region hierarchy over the supervoxel grid (host side of the pre-pass): a supervoxel without any cloud
-// cell takes the largest level L <= max_level for which the whole aligned cube of 2^L supervoxels per
-// edge around it (clipped at the grid) is cloud-free; the members of such a cube share one region whose
-// majorant is the maximum over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out.
-void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>& maj,
-                   const std::vector<uint8_t>& cloudy, std::vector<uint8_t>& lvl)
+// Region hierarchy over the supervoxel grid (host side of the pre-pass), built bottom-up: the aligned cube of
+// 2^L supervoxels per edge (clipped at the grid) becomes one region if all its members are regions of level
+// L-1 and (M - mean k_tot) * (2^L * edge) <= tau — the optical depth of null collisions a photon crossing it
+// would meet. Clear air merges at any size, homogeneous cloud too; cloud edges keep their fine supervoxels.
+// maj: pairs {M, 1/M} per supervoxel in, per region out. Double arithmetic in a fixed order: the oracle's
+// copy of this routine must decide identically.
+void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>& maj, const std::vector<double>& ksum,
+                   const std::vector<int>& kcnt, float edge, float tau, std::vector<uint8_t>& lvl)
 {
     std::fill(lvl.begin(), lvl.end(), (uint8_t)0);
     for (int L = 1; L <= max_level; ++L)
@@ -1274,17 +1278,22 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
                 for (int bi = 0; bi < nci; bi += sz)
                 {
                     const int k1 = std::min(bk + sz, nck), j1 = std::min(bj + sz, ncj), i1 = std::min(bi + sz, nci);
-                    bool clear = true;
+                    bool ok = true;
                     float m = 0.0f;
-                    for (int k = bk; k < k1 && clear; ++k)
-                        for (int j = bj; j < j1 && clear; ++j)
+                    double sum = 0.0;
+                    long long cnt = 0;
+                    for (int k = bk; k < k1 && ok; ++k)
+                        for (int j = bj; j < j1 && ok; ++j)
                             for (int i = bi; i < i1; ++i)
                             {
                                 const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                if (cloudy[e]) { clear = false; break; }
+                                if (lvl[e] != L - 1) { ok = false; break; }
                                 if (maj[e].x > m) m = maj[e].x;
+                                sum += ksum[e];
+                                cnt += kcnt[e];
                             }
-                    if (!clear) continue;
+                    if (!ok) continue;
+                    if (((double)m - sum / (double)cnt) * (double)edge * (double)sz > (double)tau) continue;
                     for (int k = bk; k < k1; ++k)
                         for (int j = bj; j < j1; ++j)
                             for (int i = bi; i < i1; ++i)
@@ -1325,29 +1334,30 @@ int build_majorants(rt_context* c)
     }
     if (ncoarse)
     {
-        hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)ncoarse), dim3(64), 0, c->stream,
-                           c->d_cells, c->d_maj, c->d_lvl, c->itot, c->jtot, (uint32_t)c->ncol, s.k_lo, s.k_hi + 1,
-                           c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
-        RT_HIP(hipGetLastError());
-        // merge cloud-free supervoxels into regions (small: one entry per supervoxel), on the host
+        double* d_ksum = nullptr;
+        int* d_kcnt = nullptr;
+        RT_HIP(hipMalloc(&d_ksum, sizeof(double) * ncoarse));
+        RT_HIP(hipMalloc(&d_kcnt, sizeof(int) * ncoarse));
+        hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)((ncoarse + 63) / 64)), dim3(64), 0, c->stream,
+                           c->d_cells, c->d_maj, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, (uint32_t)c->ncol,
+                           s.k_lo, s.k_hi + 1, c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
+        hipError_t e = hipGetLastError();
+        // merge supervoxels into regions (small: one entry per supervoxel), on the host
         std::vector<float2> h_maj(ncoarse);
-        std::vector<uint8_t> h_cloudy(ncoarse), h_lvl(ncoarse);
-        RT_HIP(hipMemcpyAsync(h_maj.data(), c->d_maj, sizeof(float2) * ncoarse, hipMemcpyDeviceToHost, c->stream));
-        RT_HIP(hipMemcpyAsync(h_cloudy.data(), c->d_lvl, ncoarse, hipMemcpyDeviceToHost, c->stream));
-        RT_HIP(hipStreamSynchronize(c->stream));
-        int levels = c->levels;
-        if (levels < 0)
-        {
-            // automatic: merging pays in sparse cloud fields and costs a little in dense ones
-            std::vector<float2> trial(h_maj);
-            build_regions(s.nci, s.ncj, s.nck, 3, trial, h_cloudy, h_lvl);
-            size_t merged = 0;
-            for (size_t e = 0; e < ncoarse; ++e) merged += h_lvl[e] >= 1;
-            levels = 3 * merged >= ncoarse ? 3 : 0;
-        }
-        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_cloudy, h_lvl);
+        std::vector<double> h_ksum(ncoarse);
+        std::vector<int> h_kcnt(ncoarse);
+        std::vector<uint8_t> h_lvl(ncoarse);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_maj.data(), c->d_maj, sizeof(float2) * ncoarse, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_ksum.data(), d_ksum, sizeof(double) * ncoarse, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_kcnt.data(), d_kcnt, sizeof(int) * ncoarse, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_ksum);
+        (void)hipFree(d_kcnt);
+        RT_HIP(e);
+        build_regions(s.nci, s.ncj, s.nck, c->levels > 0 ? c->levels : 0, h_maj, h_ksum, h_kcnt, s.hx,
+                      (float)((double)c->merge_tau_milli / 1000.0), h_lvl);
         c->hier = false;
-        for (size_t e = 0; e < ncoarse && !c->hier; ++e) c->hier = h_lvl[e] > 0;
+        for (size_t i = 0; i < ncoarse && !c->hier; ++i) c->hier = h_lvl[i] > 0;
         RT_HIP(hipMemcpyAsync(c->d_maj, h_maj.data(), sizeof(float2) * ncoarse, hipMemcpyHostToDevice, c->stream));
         RT_HIP(hipMemcpyAsync(c->d_lvl, h_lvl.data(), ncoarse, hipMemcpyHostToDevice, c->stream));
         RT_HIP(hipStreamSynchronize(c->stream));
@@ -1528,8 +1538,14 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "levels"))
     {
-        if (value < -1 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,6]", value);
+        if (value < 0 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [0,6]", value);
         c->levels = (int)value;
+        c->maj_dirty = true;
+    }
+    else if (!strcmp(name, "merge_tau_milli"))
+    {
+        if (value < 0 || value > 1000000) return fail(RT_ERR_ARG, "rt_set_option: merge_tau_milli %lld outside [0,1000000]", value);
+        c->merge_tau_milli = (int)value;
         c->maj_dirty = true;
     }
     else if (!strcmp(name, "chunk"))

@@ -27,7 +27,7 @@ class OracleScene(C.Structure):
                 ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
                 ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
                 ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int),
-                ("launch_log2k", C.c_int), ("planar", C.c_int), ("levels", C.c_int)]
+                ("launch_log2k", C.c_int), ("planar", C.c_int), ("levels", C.c_int), ("merge_tau", C.c_float)]
 
 
 class OracleSlabs(C.Structure):
@@ -91,27 +91,29 @@ def new_tallies(scene):
     return out
 
 
-DEFAULT_SUPERGRID = (8, 8, 4)     # must equal the product's default (rt_set_option "supergrid_*")
+DEFAULT_SUPERGRID = (3, 3, 2)     # must equal the product's default (rt_set_option "supergrid_*")
 
 
-DEFAULT_LEVELS = -1     # the library's default of option "levels": automatic
+DEFAULT_LEVELS = 5      # the library's defaults of options "levels" and "merge_tau_milli"
+DEFAULT_MERGE_TAU = 2.0
 
 
 def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False,
-                 levels=DEFAULT_LEVELS) -> OracleScene:
+                 levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleScene:
     f = np.float32
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
-                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar), int(levels))
+                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar), int(levels), float(merge_tau))
 
 
 def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False,
-                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False, levels=DEFAULT_LEVELS):
+                  supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False, levels=DEFAULT_LEVELS,
+                  merge_tau=DEFAULT_MERGE_TAU):
     """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
     t = tallies if tallies is not None else new_tallies(scene)
     ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
-    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar, levels)
+    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar, levels, merge_tau)
     fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
                                    seed, pid_begin, count, nthreads,
@@ -121,10 +123,10 @@ def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed
     return t, dict(zip(EVENT_NAMES, (int(v) for v in ev)))
 
 
-def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID, levels=DEFAULT_LEVELS) -> OracleSlabs:
+def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID, levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleSlabs:
     """Slabs + majorant grid; `.maj_array` holds a copy of the {M, 1/M} pairs [nck, ncj, nci, 2] and
     `.lvl_array` the region levels [nck, ncj, nci]."""
-    sc = oracle_scene(scene, supergrid=supergrid, levels=levels)
+    sc = oracle_scene(scene, supergrid=supergrid, levels=levels, merge_tau=merge_tau)
     sl = OracleSlabs()
     kg, kc, _, asy = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     lib().oracle_build_slabs(C.byref(sc), _p(kg, C.c_float), _p(kc, C.c_float), _p(asy, C.c_float), C.byref(sl))

@@ -199,21 +199,25 @@ def test_planar_mode_bit_identical_to_oracle(rt, n, supergrid):
 
 
 @pytest.mark.parametrize("pool", [0, 128])
-@pytest.mark.parametrize("scene_name,n,supergrid,levels", [
-    ("block_cloud", 1 << 18, (8, 8, 4), 0), ("block_cloud", 1 << 18, (8, 8, 4), 1), ("block_cloud", 1 << 18, (8, 8, 4), 3),
-    ("block_cloud", 1 << 17, (4, 4, 2), 4), ("cumulus_small", 1 << 17, (8, 8, 4), 3), ("cumulus_small", 1 << 17, (2, 2, 2), 2),
-    ("tiny", 1 << 16, (1, 1, 1), 3), ("tiny", 1 << 16, (5, 3, 2), 1), ("cloud_to_top", 1 << 15, (4, 4, 1), 2)])
-def test_region_hierarchy_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid, levels):
-    """Cloud-free supervoxels merged into cubes of up to 2^levels per edge (option "levels"): fewer, larger
-    majorant regions; the levels, the region majorants and every tally must equal the oracle's."""
+@pytest.mark.parametrize("scene_name,n,supergrid,levels,tau_milli", [
+    ("block_cloud", 1 << 18, (8, 8, 4), 0, 500), ("block_cloud", 1 << 18, (8, 8, 4), 1, 500), ("block_cloud", 1 << 18, (4, 4, 4), 4, 500),
+    ("block_cloud", 1 << 17, (4, 4, 2), 5, 0), ("cumulus_small", 1 << 17, (4, 4, 4), 4, 500), ("cumulus_small", 1 << 17, (2, 2, 2), 3, 2000),
+    ("cumulus_small", 1 << 17, (4, 4, 2), 4, 37), ("tiny", 1 << 16, (1, 1, 1), 3, 500), ("tiny", 1 << 16, (5, 3, 2), 1, 100000),
+    ("cloud_to_top", 1 << 15, (4, 4, 1), 2, 500), ("rayleigh_absorbing", 1 << 16, (8, 8, 4), 4, 500)])
+def test_region_hierarchy_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid, levels, tau_milli):
+    """Supervoxels merged bottom-up into cubes of up to 2^levels per edge where (M - mean k) * edge <= tau
+    (options "levels", "merge_tau_milli"): fewer, larger majorant regions away from cloud edges. The levels,
+    the region majorants and every tally must equal the oracle's."""
     scene = SCENES[scene_name](rt.scenes)
-    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels, merge_tau_milli=tau_milli)
     tr.set_supergrid(*supergrid)
-    osl = O.oracle_slabs(scene, supergrid=supergrid, levels=levels)
-    assert np.array_equal(tr.region_levels(), osl.lvl_array) and int(osl.lvl_array.max()) <= levels
-    assert np.array_equal(tr.majorants().view(np.uint32), osl.maj_array.view(np.uint32))
+    tau = np.float32(tau_milli / 1000.0)
+    osl = O.oracle_slabs(scene, supergrid=supergrid, levels=levels, merge_tau=tau)
+    if osl.lvl_array is not None:
+        assert np.array_equal(tr.region_levels(), osl.lvl_array) and int(osl.lvl_array.max()) <= levels
+        assert np.array_equal(tr.majorants().view(np.uint32), osl.maj_array.view(np.uint32))
     tr.trace(99, 123_456_789_000, n); tr.synchronize()
-    want, ev = O.photon_oracle(scene, 99, 123_456_789_000, n, supergrid=supergrid, levels=levels)
+    want, ev = O.photon_oracle(scene, 99, 123_456_789_000, n, supergrid=supergrid, levels=levels, merge_tau=tau)
     _assert_same(tr.tallies(), want)
     assert tr.events() == ev
     tr.close()

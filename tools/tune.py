@@ -22,7 +22,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=128, chunk=256, levels=2, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=8, supergrid_y=8, supergrid_z=4)
+base = dict(pool=128, chunk=256, levels=5, merge_tau_milli=2000, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=3, supergrid_y=3, supergrid_z=2)
 for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
     if "=" in kv:
         base[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -43,6 +43,21 @@ elif what == "pool2":
 elif what == "launch2":
     for lk in (-1, 3, 5, 6, 7, 8):
         o = dict(base, pool=128, launch_log2k=lk); res.append((run(o, 3), lk))
+elif what == "merge":
+    for sg in ((4, 4, 4), (4, 4, 2), (8, 8, 4), (2, 2, 2)):
+        for tau in (100, 500, 2000):
+            o = dict(base, pool=128, levels=4, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
+            res.append((run(o, 3),) + sg + (tau,))
+elif what == "merge2":
+    for sg, lv in (((4, 4, 2), 4), ((2, 2, 2), 5), ((4, 4, 4), 4), ((2, 2, 1), 5), ((4, 4, 2), 5)):
+        for tau in (2000, 4000, 8000, 16000):
+            o = dict(base, pool=128, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
+            res.append((run(o, 3),) + sg + (lv, tau))
+elif what == "merge3":
+    for sg, lv in (((4, 4, 2), 4), ((3, 3, 2), 5), ((4, 4, 3), 4), ((2, 2, 2), 5), ((3, 3, 3), 5), ((4, 2, 2), 5)):
+        for tau in (1000, 2000, 3000):
+            o = dict(base, pool=128, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
+            res.append((run(o, 3),) + sg + (lv, tau))
 elif what == "levels":
     for lv in (0, 1, 2, 3, 4):
         o = dict(base, pool=128, levels=lv); res.append((run(o, 3), lv))
@@ -58,6 +73,6 @@ elif what == "blocks":
     for b in (2, 3, 4, 5, 6, 7, 8, 10, 12):
         o = dict(base, blocks_per_cu=b); res.append((run(o), b))
 res.sort()
-for r in res[:16]:
+for r in res[:24]:
     print(wl, what, "ms=%.3f" % r[0], "Gph/s=%.3f" % (n / r[0] / 1e6), r[1:])
 print("worst", res[-1])
