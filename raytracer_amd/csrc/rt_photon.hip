@@ -1190,13 +1190,15 @@ struct rt_context
     float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
     uint8_t* d_lvl = nullptr;         // region level per supervoxel (also the scratch of the cloud flags)
-    int levels = 5;                   // largest region: cubes of 2^levels supervoxels per edge (0 = no merging)
+    int levels = -1;                  // largest region: cubes of 2^levels supervoxels per edge (0 = no merging,
+                                      // -1 = automatic: 5 or 0)
     int merge_tau_milli = 2000;       // merge criterion: (M - mean k_tot) * edge <= merge_tau_milli / 1000
     bool hier = false;                // any region larger than a supervoxel (selects the kernel variant)
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
-    int sgx = 3, sgy = 3, sgz = 2;    // supervoxel size in cells (0 = no grid, slabs only): fine, because
-                                      // build_regions merges them wherever the field is homogeneous
+    int sgx = -1, sgy = -1, sgz = -1; // supervoxel size in cells (0 = no grid, slabs only; -1 = automatic:
+                                      // 3x3x2 merged by build_regions, or 8x8x4 unmerged, see build_majorants)
+    bool built_for_stratified = false; // launch mode the automatic choices were made for
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
@@ -1309,15 +1311,24 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
 int build_majorants(rt_context* c)
 {
     rt_slab_info& s = c->slabs;
-    const int g = (s.k_lo >= 0 && c->sgx > 0 && c->sgy > 0 && c->sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
+    // Automatic choices (options left at -1). Fine supervoxels with merged regions need their 9-byte-per-
+    // supervoxel tables cache-resident: the stratified launch order provides that on any grid, a grid that
+    // fits the Infinity Cache too. Uniform launch positions over a larger grid (every access a miss) do better
+    // with the coarse grid and no merging — measured on 1024x1024x128: 3.60 vs 2.28 G photons/s.
+    const bool fine = c->launch_log2k >= 0 || 16ull * (unsigned long long)c->ncell <= (256ull << 20);
+    const int sgx = c->sgx >= 0 ? c->sgx : (fine ? 3 : 8), sgy = c->sgy >= 0 ? c->sgy : (fine ? 3 : 8),
+              sgz = c->sgz >= 0 ? c->sgz : (fine ? 2 : 4);
+    const int levels = c->levels >= 0 ? c->levels : (fine ? 5 : 0);
+    c->built_for_stratified = c->launch_log2k >= 0;
+    const int g = (s.k_lo >= 0 && sgx > 0 && sgy > 0 && sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
     s.gslab = g; s.nci = s.ncj = s.nck = 0; s.hx = s.hy = s.hz = 0.0f;
     size_t ncoarse = 0;
     if (g >= 0)
     {
-        s.nci = (c->itot + c->sgx - 1) / c->sgx;
-        s.ncj = (c->jtot + c->sgy - 1) / c->sgy;
-        s.nck = (s.k_hi + 1 - s.k_lo + c->sgz - 1) / c->sgz;
-        s.hx = (float)c->sgx * c->dx; s.hy = (float)c->sgy * c->dy; s.hz = (float)c->sgz * c->dz;
+        s.nci = (c->itot + sgx - 1) / sgx;
+        s.ncj = (c->jtot + sgy - 1) / sgy;
+        s.nck = (s.k_hi + 1 - s.k_lo + sgz - 1) / sgz;
+        s.hx = (float)sgx * c->dx; s.hy = (float)sgy * c->dy; s.hz = (float)sgz * c->dz;
         ncoarse = (size_t)s.nci * s.ncj * s.nck;
         if (s.nci > 32767 || s.ncj > 32767 || ncoarse >= (1ull << 31))
             return fail(RT_ERR_ARG, "majorant grid %dx%dx%d too large", s.nci, s.ncj, s.nck);
@@ -1340,7 +1351,7 @@ int build_majorants(rt_context* c)
         RT_HIP(hipMalloc(&d_kcnt, sizeof(int) * ncoarse));
         hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)((ncoarse + 63) / 64)), dim3(64), 0, c->stream,
                            c->d_cells, c->d_maj, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, (uint32_t)c->ncol,
-                           s.k_lo, s.k_hi + 1, c->sgx, c->sgy, c->sgz, s.nci, s.ncj);
+                           s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
         hipError_t e = hipGetLastError();
         // merge supervoxels into regions (small: one entry per supervoxel), on the host
         std::vector<float2> h_maj(ncoarse);
@@ -1354,7 +1365,7 @@ int build_majorants(rt_context* c)
         (void)hipFree(d_ksum);
         (void)hipFree(d_kcnt);
         RT_HIP(e);
-        build_regions(s.nci, s.ncj, s.nck, c->levels > 0 ? c->levels : 0, h_maj, h_ksum, h_kcnt, s.hx,
+        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_ksum, h_kcnt, s.hx,
                       (float)((double)c->merge_tau_milli / 1000.0), h_lvl);
         c->hier = false;
         for (size_t i = 0; i < ncoarse && !c->hier; ++i) c->hier = h_lvl[i] > 0;
@@ -1535,10 +1546,11 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     {
         if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
         c->launch_log2k = (int)value;
+        if ((value >= 0) != c->built_for_stratified) c->maj_dirty = true;      // the automatic grid depends on it
     }
     else if (!strcmp(name, "levels"))
     {
-        if (value < 0 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [0,6]", value);
+        if (value < -1 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,6]", value);
         c->levels = (int)value;
         c->maj_dirty = true;
     }
@@ -1566,7 +1578,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "supergrid_x") || !strcmp(name, "supergrid_y") || !strcmp(name, "supergrid_z"))
     {
-        if (value < 0 || value > 4096) return fail(RT_ERR_ARG, "rt_set_option: %s %lld outside [0,4096]", name, value);
+        if (value < -1 || value > 4096) return fail(RT_ERR_ARG, "rt_set_option: %s %lld outside [-1,4096]", name, value);
         (name[10] == 'x' ? c->sgx : (name[10] == 'y' ? c->sgy : c->sgz)) = (int)value;
         c->maj_dirty = true;
     }

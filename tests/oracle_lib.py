@@ -91,16 +91,28 @@ def new_tallies(scene):
     return out
 
 
-DEFAULT_SUPERGRID = (3, 3, 2)     # must equal the product's default (rt_set_option "supergrid_*")
+DEFAULT_SUPERGRID = "auto"        # must equal the product's default (rt_set_option "supergrid_*")
 
 
-DEFAULT_LEVELS = 5      # the library's defaults of options "levels" and "merge_tau_milli"
+DEFAULT_LEVELS = "auto"      # the library's defaults of options "levels" and "merge_tau_milli"
 DEFAULT_MERGE_TAU = 2.0
+
+
+def resolve_auto(scene, supergrid, levels, launch_log2k):
+    """The library's automatic choices (build_majorants in rt_photon.hip), restated: fine supervoxels with merged
+    regions when the launch is stratified or the packed cells fit the Infinity Cache, else coarse and unmerged."""
+    fine = launch_log2k >= 0 or 16 * scene.ncell <= (256 << 20)
+    if isinstance(supergrid, str):
+        supergrid = (3, 3, 2) if fine else (8, 8, 4)
+    if isinstance(levels, str):
+        levels = 5 if fine else 0
+    return supergrid, levels
 
 
 def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False,
                  levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleScene:
     f = np.float32
+    supergrid, levels = resolve_auto(scene, supergrid, levels, launch_log2k)
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),

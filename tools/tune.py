@@ -22,7 +22,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=128, chunk=256, levels=5, merge_tau_milli=2000, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=3, supergrid_y=3, supergrid_z=2)
+base = dict(pool=128, chunk=256, levels=-1, merge_tau_milli=2000, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=-1, supergrid_y=-1, supergrid_z=-1)
 for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
     if "=" in kv:
         base[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -32,7 +32,7 @@ if what == "thresholds":
     for te, ts_, lo in itertools.product((8, 16, 24, 32, 48), (8, 16, 24, 32), (8, 16, 32)):
         o = dict(base, th_event=te, th_scatter=ts_, low_traverse=lo); res.append((run(o), te, ts_, lo))
 elif what == "grid":
-    for sg in ((0, 0, 0), (4, 4, 2), (4, 4, 4), (8, 8, 2), (8, 8, 4), (8, 8, 8), (16, 16, 4), (16, 16, 8), (32, 32, 8), (2, 2, 2)):
+    for sg in ((0, 0, 0), (3, 3, 2), (4, 4, 2), (4, 4, 4), (6, 6, 4), (8, 8, 4), (8, 8, 8), (12, 12, 8), (16, 16, 8)):
         o = dict(base, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2]); res.append((run(o),) + sg)
 elif what == "pool":
     for pl, b in ((0, 32), (64, 32), (64, 24), (96, 32), (96, 20), (96, 16), (128, 32), (128, 16), (128, 12), (160, 32), (160, 12), (192, 32), (256, 32)):
