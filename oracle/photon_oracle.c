@@ -289,6 +289,17 @@ static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, 
                             }
                 }
     }
+    /* The level rides in the three low mantissa bits of M, rounded UP to make room (still a majorant, larger
+     * by < 1e-6), and 1/M is taken from the packed value: one 8-byte table entry tells a traverse step
+     * everything about its region. */
+    for (size_t e = 0; e < n; ++e)
+    {
+        uint32_t bits;
+        memcpy(&bits, &maj[2 * e], 4);
+        bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
+        memcpy(&maj[2 * e], &bits, 4);
+        maj[2 * e + 1] = 1.0f / maj[2 * e];
+    }
 }
 
 /* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
@@ -500,7 +511,13 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         /* the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck), clipped at the grid */
         int L = 0;
         size_t e = 0;
-        if (gridded) { e = ((size_t)ck * ncj + cj) * nci + ci; L = sl->lvl[e]; }
+        if (gridded)
+        {
+            e = ((size_t)ck * ncj + cj) * nci + ci;
+            uint32_t mbits;
+            memcpy(&mbits, &sl->maj[2 * e], 4);
+            L = (int)(mbits & 7u);
+        }
         const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
         const int bx1 = bx0 + (1 << L) < nci ? bx0 + (1 << L) : nci, by1 = by0 + (1 << L) < ncj ? by0 + (1 << L) : ncj,
                   bz1 = bz0 + (1 << L) < nck ? bz0 + (1 << L) : nck;

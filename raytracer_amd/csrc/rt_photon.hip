@@ -66,9 +66,9 @@ struct TraceArgs
     const float4* cells;      // {k_tot = gas + cloud, ssa, asy, k_cloud} per cell [k][j][i]: one 16-byte
                               // record, so a collision costs one memory sector however it ends
     const float2* maj;        // {M, 1/M} of the region a supervoxel belongs to: ncoarse supervoxels
-                              // [ck][cj][ci], then one entry per slab
-    const uint8_t* lvl;       // region level per supervoxel: its region is the aligned cube of 2^lvl
-                              // supervoxels per edge around it (cloud-free supervoxels merged)
+                              // [ck][cj][ci], then one entry per slab. The three low mantissa bits of a
+                              // supervoxel's M hold its region level: the region is the aligned cube of 2^level
+                              // supervoxels per edge around it
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
     uint64_t seed;
@@ -408,7 +408,7 @@ rt_trace_kernel(const TraceArgs a)
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
                     // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck)
-                    const int L = gridded ? (int)a.lvl[e] : 0;
+                    const int L = gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0;
                     const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
                     const int bx1 = min(bx0 + (1 << L), a.nci), by1 = min(by0 + (1 << L), a.ncj), bz1 = min(bz0 + (1 << L), a.nck);
                     // the face ahead on each axis: index of the cell face, then its coordinate
@@ -910,7 +910,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const float2 mm = a.maj[e];
                     // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck); the
                     // variant without merged regions (HIER = false) skips the level fetch and the cube arithmetic
-                    const int L = HIER && gridded ? (int)a.lvl[e] : 0;
+                    const int L = HIER && gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0;
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1;
                     if (HIER)
                     {
@@ -1202,7 +1202,7 @@ struct rt_context
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = 128;                   // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
-    int th_launch = 32;               // pool kernel: free slots that trigger a launch round
+    int th_launch = 40;               // pool kernel: free slots that trigger a launch round
     bool planar = false;                // 2D tracer's scattering rule (pool kernel only)
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
@@ -1305,6 +1305,17 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
                                 maj[e] = make_float2(m, 1.0f / m);
                             }
                 }
+    }
+    // The level rides in the three low mantissa bits of M, rounded UP to make room (still a majorant, larger
+    // by < 1e-6), and 1/M is taken from the packed value: one 8-byte table entry tells a traverse round
+    // everything about its region (a second table cost a second cache line per round).
+    for (size_t e = 0; e < maj.size(); ++e)
+    {
+        uint32_t bits;
+        memcpy(&bits, &maj[e].x, 4);
+        bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
+        memcpy(&maj[e].x, &bits, 4);
+        maj[e].y = 1.0f / maj[e].x;
     }
 }
 
@@ -1630,7 +1641,6 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     a.nslab = c->slabs.nslab;
     for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
     a.maj = c->d_maj;
-    a.lvl = c->d_lvl;
     a.gslab = c->slabs.gslab;
     a.nci = c->slabs.nci; a.ncj = c->slabs.ncj; a.nck = c->slabs.nck;
     a.ncoarse = (uint32_t)c->ncoarse;

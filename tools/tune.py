@@ -22,7 +22,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=128, chunk=256, levels=-1, merge_tau_milli=2000, launch_log2k=-1, th_launch=32, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=-1, supergrid_y=-1, supergrid_z=-1)
+base = dict(pool=128, chunk=256, levels=-1, merge_tau_milli=2000, launch_log2k=-1, th_launch=40, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=-1, supergrid_y=-1, supergrid_z=-1)
 for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
     if "=" in kv:
         base[kv.split("=")[0]] = int(kv.split("=")[1])
@@ -58,6 +58,9 @@ elif what == "merge3":
         for tau in (1000, 2000, 3000):
             o = dict(base, pool=128, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
             res.append((run(o, 3),) + sg + (lv, tau))
+elif what == "thl":
+    for thl in (16, 24, 32, 40, 48, 64):
+        o = dict(base, pool=128, th_launch=thl); res.append((run(o, 3), thl))
 elif what == "levels":
     for lv in (0, 1, 2, 3, 4):
         o = dict(base, pool=128, levels=lv); res.append((run(o, 3), lv))
