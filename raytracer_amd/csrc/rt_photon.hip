@@ -556,6 +556,128 @@ enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 
 constexpr int kPoolRec = 16;
 constexpr int kPoolBlock = 64;
 
+// One traverse step of the pool kernel on the photon held in the lane's locals (x, y, z, tau, ux, uy, uz, nstep,
+// ci, cj, ck, slab, diffuse, w11, ns): cross one majorant region or stop at the collision site; IX, IY, IZ are the
+// direction reciprocals. Used by the traverse stage and, fused, at the end of the new-direction stage (a photon
+// that has just been given a direction always traverses next: doing it in the same round saves the slot
+// selection and the LDS round trip of one round per scattering). The region is the aligned cube of 2^L
+// supervoxels per edge around (ci, cj, ck); HIER = false skips the level and the cube arithmetic. Inside a
+// merged region the supervoxel indices follow the position (kept within the region: a coordinate on one of
+// its faces may round to the neighbour's side).
+#define RT_TRAVERSE_STEP(IX, IY, IZ) \
+                if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
+                { \
+                    tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]); \
+                    ns = PS_LAUNCH; \
+                } \
+                else \
+                { \
+                    ++nstep; \
+                    if (STATS) ++ev_step; \
+                    const bool gridded = slab == a.gslab; \
+                    const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab; \
+                    const float2 mm = a.maj[e]; \
+                    const int L = HIER && gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
+                    int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
+                    if (HIER) \
+                    { \
+                        bx0 = (ci >> L) << L; by0 = (cj >> L) << L; bz0 = (ck >> L) << L; \
+                        bx1 = min(bx0 + (1 << L), a.nci); by1 = min(by0 + (1 << L), a.ncj); bz1 = min(bz0 + (1 << L), a.nck); \
+                    } \
+                    const int cfx = (IX) > 0.0f ? bx1 : bx0, cfy = (IY) > 0.0f ? by1 : by0; \
+                    const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx; \
+                    const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy; \
+                    const bool up = (IZ) > 0.0f; \
+                    float fz; \
+                    if (gridded) \
+                    { \
+                        const int cfz = up ? bz1 : bz0; \
+                        fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0); \
+                    } \
+                    else \
+                    { \
+                        const int fi = up ? slab + 1 : slab; \
+                        fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3])); \
+                    } \
+                    const float tx = gridded ? face_distance(fx, x, (IX)) : __builtin_inff(); \
+                    const float ty = gridded ? face_distance(fy, y, (IY)) : __builtin_inff(); \
+                    const float tz = face_distance(fz, z, (IZ)); \
+                    float t_exit = tx; int axis = 0; \
+                    if (ty < t_exit) { t_exit = ty; axis = 1; } \
+                    if (tz < t_exit) { t_exit = tz; axis = 2; } \
+                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff(); \
+                    const bool hit = t_exit <= dn; \
+                    const float tt = hit ? t_exit : dn; \
+                    x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z); \
+                    if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); } \
+                    if (HIER && L > 0) \
+                    { \
+                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1); \
+                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1); \
+                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1); \
+                    } \
+                    w11 = __float_as_uint(mm.y); \
+                    if (!hit) \
+                        ns = PS_COLLIDE; \
+                    else \
+                    { \
+                        if (STATS) ++ev_trans; \
+                        tau = fma_(-tt, mm.x, tau); \
+                        tau = tau > 0.0f ? tau : 0.0f; \
+                        int leave = 0; \
+                        if (axis == 0) \
+                        { \
+                            x = fx; ci = (IX) > 0.0f ? bx1 : bx0 - 1; \
+                            if (ci == a.nci) { ci = 0; x = 0.0f; } \
+                            if (ci < 0) { ci = a.nci - 1; x = a.xs; } \
+                        } \
+                        else if (axis == 1) \
+                        { \
+                            y = fy; cj = (IY) > 0.0f ? by1 : by0 - 1; \
+                            if (cj == a.ncj) { cj = 0; y = 0.0f; } \
+                            if (cj < 0) { cj = a.ncj - 1; y = a.ys; } \
+                        } \
+                        else \
+                        { \
+                            z = fz; \
+                            if (gridded) \
+                            { \
+                                const int nk = up ? bz1 : bz0 - 1; \
+                                if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1; \
+                            } \
+                            else \
+                                leave = up ? 1 : -1; \
+                        } \
+                        if (__builtin_expect(leave != 0, 0)) \
+                        { \
+                            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot); \
+                            const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot; \
+                            if (leave > 0 && slab == a.nslab - 1) \
+                            { \
+                                if (STATS) ++ev_toa; \
+                                tally_add(&a.tallies[a.ncol + ij]); \
+                                ns = PS_LAUNCH; \
+                            } \
+                            else if (leave < 0 && slab == 0) \
+                            { \
+                                if (STATS) ++ev_sfc; \
+                                w11 = ij; \
+                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]); \
+                                ns = PS_SURFACE; \
+                            } \
+                            else \
+                            { \
+                                slab += leave; \
+                                if (slab == a.gslab) \
+                                { \
+                                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); \
+                                    ck = leave > 0 ? 0 : a.nck - 1; \
+                                } \
+                            } \
+                        } \
+                    } \
+                }
+
 template <bool FIXED_DOT, bool STATS, int NS, bool HIER>
 __global__ void __launch_bounds__(kPoolBlock)
 rt_trace_pool_kernel(const TraceArgs a)
@@ -696,10 +818,23 @@ rt_trace_pool_kernel(const TraceArgs a)
                     uy = mu * cp;
                     uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
-                R4(1) = make_float4(ux, uy, uz, g1.w);
-                R4(2) = make_float4(dir_reciprocal(ux), dir_reciprocal(uy), dir_reciprocal(uz), 0.0f);
-                RW(13) = (cks | (1u << 24)) & ~(1u << 25);      // diffuse from now on
+                // diffuse from now on; then the photon's next traverse step at once
+                const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
+                const float4 g0 = R4(0);
+                const uint32_t cicj = RW(12);
+                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
+                uint32_t nstep = __float_as_uint(g1.w);
+                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
+                int slab = (int)((cks >> 16) & 0xffu);
+                const bool diffuse = true;
+                uint32_t w11 = 0u;
                 ns = PS_TRAVERSE;
+                RT_TRAVERSE_STEP(ix, iy, iz)
+                R4(0) = make_float4(x, y, z, tau);
+                R4(1) = make_float4(ux, uy, uz, __uint_as_float(nstep));
+                R4(2) = make_float4(ix, iy, iz, __uint_as_float(w11));
+                RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (1u << 24);
             }
         }
         else if (cls == 1u)
@@ -895,127 +1030,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const bool diffuse = (cks >> 24) & 1u;
                 ns = PS_TRAVERSE;
                 uint32_t w11 = RW(11);
-                if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0))
-                {
-                    tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]);
-                    ns = PS_LAUNCH;
-                }
-                else
-                {
-                    ++nstep;
-                    if (STATS) ++ev_step;
-                    // ---- cross one majorant region or stop at the collision site ----
-                    const bool gridded = slab == a.gslab;
-                    const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
-                    const float2 mm = a.maj[e];
-                    // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck); the
-                    // variant without merged regions (HIER = false) skips the level fetch and the cube arithmetic
-                    const int L = HIER && gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0;
-                    int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1;
-                    if (HIER)
-                    {
-                        bx0 = (ci >> L) << L; by0 = (cj >> L) << L; bz0 = (ck >> L) << L;
-                        bx1 = min(bx0 + (1 << L), a.nci); by1 = min(by0 + (1 << L), a.ncj); bz1 = min(bz0 + (1 << L), a.nck);
-                    }
-                    const int cfx = g2.x > 0.0f ? bx1 : bx0, cfy = g2.y > 0.0f ? by1 : by0;
-                    const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
-                    const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy;
-                    const bool up = g2.z > 0.0f;
-                    float fz;
-                    if (gridded)
-                    {
-                        const int cfz = up ? bz1 : bz0;
-                        fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0);
-                    }
-                    else
-                    {
-                        const int fi = up ? slab + 1 : slab;
-                        fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3]));
-                    }
-                    const float tx = gridded ? face_distance(fx, x, g2.x) : __builtin_inff();
-                    const float ty = gridded ? face_distance(fy, y, g2.y) : __builtin_inff();
-                    const float tz = face_distance(fz, z, g2.z);
-                    float t_exit = tx; int axis = 0;
-                    if (ty < t_exit) { t_exit = ty; axis = 1; }
-                    if (tz < t_exit) { t_exit = tz; axis = 2; }
-                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff();   // raytracer_kernels.cu:367
-                    const bool hit = t_exit <= dn;
-                    const float tt = hit ? t_exit : dn;
-                    x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
-                    if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
-                    if (HIER && L > 0)
-                    {
-                        // inside a merged region the supervoxel indices follow the position (kept within the
-                        // region: a coordinate on one of its faces may round to the neighbour's side)
-                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1);
-                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1);
-                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1);
-                    }
-                    w11 = __float_as_uint(mm.y);
-
-                    if (!hit)
-                        ns = PS_COLLIDE;
-                    else
-                    {
-                        if (STATS) ++ev_trans;
-                        tau = fma_(-tt, mm.x, tau);
-                        tau = tau > 0.0f ? tau : 0.0f;
-                        int leave = 0;
-                        if (axis == 0)
-                        {
-                            x = fx; ci = g2.x > 0.0f ? bx1 : bx0 - 1;
-                            if (ci == a.nci) { ci = 0; x = 0.0f; }
-                            if (ci < 0) { ci = a.nci - 1; x = a.xs; }
-                        }
-                        else if (axis == 1)
-                        {
-                            y = fy; cj = g2.y > 0.0f ? by1 : by0 - 1;
-                            if (cj == a.ncj) { cj = 0; y = 0.0f; }
-                            if (cj < 0) { cj = a.ncj - 1; y = a.ys; }
-                        }
-                        else
-                        {
-                            z = fz;
-                            if (gridded)
-                            {
-                                const int nk = up ? bz1 : bz0 - 1;
-                                if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1;
-                            }
-                            else
-                                leave = up ? 1 : -1;
-                        }
-                        if (__builtin_expect(leave != 0, 0))
-                        {
-                            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                            const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
-                            if (leave > 0 && slab == a.nslab - 1)
-                            {
-                                // top of the atmosphere, raytracer_kernels.cu:487-499
-                                if (STATS) ++ev_toa;
-                                tally_add(&a.tallies[a.ncol + ij]);
-                                ns = PS_LAUNCH;
-                            }
-                            else if (leave < 0 && slab == 0)
-                            {
-                                // surface arrival, raytracer_kernels.cu:455-460
-                                if (STATS) ++ev_sfc;
-                                w11 = ij;
-                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]);
-                                ns = PS_SURFACE;
-                            }
-                            else
-                            {
-                                // next slab, raytracer_kernels.cu:376-415
-                                slab += leave;
-                                if (slab == a.gslab)
-                                {
-                                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj);
-                                    ck = leave > 0 ? 0 : a.nck - 1;
-                                }
-                            }
-                        }
-                    }
-                }
+                RT_TRAVERSE_STEP(g2.x, g2.y, g2.z)
                 R4(0) = make_float4(x, y, z, tau);
                 RW(7) = nstep;
                 RW(11) = w11;
