@@ -1373,12 +1373,15 @@ int build_majorants(rt_context* c)
     {
         double* d_ksum = nullptr;
         int* d_kcnt = nullptr;
-        RT_HIP(hipMalloc(&d_ksum, sizeof(double) * ncoarse));
-        RT_HIP(hipMalloc(&d_kcnt, sizeof(int) * ncoarse));
-        hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)((ncoarse + 63) / 64)), dim3(64), 0, c->stream,
-                           c->d_cells, c->d_maj, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, (uint32_t)c->ncol,
-                           s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
-        hipError_t e = hipGetLastError();
+        hipError_t e = hipMalloc(&d_ksum, sizeof(double) * ncoarse);
+        if (e == hipSuccess) e = hipMalloc(&d_kcnt, sizeof(int) * ncoarse);
+        if (e == hipSuccess)
+        {
+            hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)((ncoarse + 63) / 64)), dim3(64), 0, c->stream,
+                               c->d_cells, c->d_maj, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, (uint32_t)c->ncol,
+                               s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
+            e = hipGetLastError();
+        }
         // merge supervoxels into regions (small: one entry per supervoxel), on the host
         std::vector<float2> h_maj(ncoarse);
         std::vector<double> h_ksum(ncoarse);
@@ -1388,8 +1391,8 @@ int build_majorants(rt_context* c)
         if (e == hipSuccess) e = hipMemcpyAsync(h_ksum.data(), d_ksum, sizeof(double) * ncoarse, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_kcnt.data(), d_kcnt, sizeof(int) * ncoarse, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d_ksum);
-        (void)hipFree(d_kcnt);
+        if (d_ksum) (void)hipFree(d_ksum);
+        if (d_kcnt) (void)hipFree(d_kcnt);
         RT_HIP(e);
         build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_ksum, h_kcnt, s.hx,
                       (float)((double)c->merge_tau_milli / 1000.0), h_lvl);
