@@ -377,6 +377,38 @@ def test_c3_cumulus_statistics_against_reference_restatement(rt):
         assert z.size > 1000 and np.max(np.abs(z)) < 6.5 and 0.9 < np.mean(z ** 2) < 1.1, (name, np.mean(z ** 2), np.max(np.abs(z)))
 
 
+def test_c4_les_grid_2p30_photons_against_reference_restatement(rt):
+    """north_star's target: >= 2^30 photons through the 1024x1024x128 LES cumulus grid (BASELINE config 4), here
+    on one GPU as four accumulating calls of 2^28 (the shards of four ranks), stratified launch. Exact
+    balance; toa_down uniform (2^30 / 2^20 per column, up to edge rounding); global fractions within 4 sigma of
+    oracle/cpu_ref.cpp (the bit-pinned restatement of raytracer_3d.cpp) on the same grid; per-level absorption
+    z-scores consistent with N(0,1)."""
+    scene = rt.scenes.cumulus_c4()
+    n = 1 << 30
+    tr = rt.PhotonTracer.from_scene(scene, launch_log2k=5)
+    for r in range(4):
+        tr.trace(23, r * (n // 4), n // 4)
+    tr.synchronize()
+    a = tr.tallies()
+    assert rt.photon_balance(a) == 0 and int(a["toa_down"].sum()) == n
+    # 1024 launches per column; a position that rounds onto a cell edge is tallied by the neighbour
+    per_col = n // (scene.itot * scene.jtot)
+    assert int(np.abs(a["toa_down"].astype(np.int64) - per_col).max()) <= 8
+    tr.close()
+    b, _ = O.cpu_ref(O.scene_to_f64(scene), 6_000_000, nthreads=0)
+    na, nb = n, int(b["toa_down"].sum())
+    for name in O.TALLY_NAMES[1:]:
+        pa, pb = int(a[name].sum()) / na, int(b[name].sum()) / nb
+        sig = np.sqrt(max(pb * (1 - pb), 1e-12) * (1 / na + 1 / nb))
+        assert abs(pa - pb) < 4 * sig, (name, pa, pb, (pa - pb) / sig)
+    la = (a["atmos_direct"] + a["atmos_diffuse"]).sum(axis=(1, 2)).astype(np.float64)
+    lb = (b["atmos_direct"] + b["atmos_diffuse"]).sum(axis=(1, 2)).astype(np.float64)
+    m = lb >= 40
+    pooled = (la + lb) / (na + nb)
+    z = ((la / na - lb / nb) / np.sqrt(pooled * (1 / na + 1 / nb)))[m]
+    assert z.size > 60 and np.max(np.abs(z)) < 5.0 and 0.5 < np.mean(z ** 2) < 1.7, (np.mean(z ** 2), np.max(np.abs(z)))
+
+
 @pytest.mark.parametrize("pool", [0, 128])
 @pytest.mark.parametrize("scene_name,n,log2k", [("tiny", 192 * 32 * 3 + 777, 5), ("tiny", 50000, 0), ("tiny", 50000, 9),
                                                 ("few_columns", 40000, 3), ("few_columns", 40000, 0),
