@@ -303,6 +303,20 @@ def test_errors_are_reported_not_fatal(rt):
         tr.set_option("no_such_option", 1)
     with pytest.raises(rt.RtError):
         tr.set_scene(zenith_deg=95.0)
+    for name, bad in (("levels", 7), ("levels", -2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
+                      ("pool", 100), ("launch_log2k", 21), ("th_launch", 0), ("supergrid_x", -2), ("pool_waves_per_cu", 0)):
+        with pytest.raises(rt.RtError, match=name):
+            tr.set_option(name, bad)
+    tr.close()
+    # a photon-id range beyond the 40 bits the pool kernel packs is refused, not truncated
+    ok = rt.PhotonTracer.from_scene(rt.scenes.tiny())
+    with pytest.raises(rt.RtError, match="40 bits"):
+        ok.trace(0, (1 << 40) - 5, 10)
+    ok.set_option("pool", 0)            # the lane-resident kernel carries full 64-bit ids
+    ok.trace(0, (1 << 40) - 5, 10); ok.synchronize()
+    want, _ = O.photon_oracle(rt.scenes.tiny(), 0, (1 << 40) - 5, 10)
+    _assert_same(ok.tallies(), want)
+    ok.close()
 
 
 def test_full_size_properties_block_cloud(rt):
