@@ -35,7 +35,7 @@ WORKLOADS = {
     # name: (scene factory name, default log2 photons per GPU per step, description)
     "c1": ("block_cloud", 26, "C1 block cloud 128x128x128 (raytracer_3d.cu built-in scene)"),
     "c2": ("rayleigh_column", 24, "C2 clear-sky Rayleigh column 64x64x64"),
-    "c3": ("cumulus_c3", 26, "C3 broken cumulus 256x256x128, HG cloud + Lambertian surface"),
+    "c3": ("cumulus_c3", 28, "C3 broken cumulus 256x256x128, HG cloud + Lambertian surface (2^28 photons on one GPU)"),
     "c4": ("cumulus_c4", 28, "C4 LES cumulus 1024x1024x128 (2^31 photons per step over 8 GPUs)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
