@@ -199,8 +199,10 @@ int rt_get_region_levels(rt_context* ctx, uint8_t* out, size_t n);
 int rt_get_events(rt_context* ctx, uint64_t out[RT_N_EVENTS]);
 
 /* Wave-scheduling statistics of "stats" launches since the last reset: rounds run and lanes
- * served per stage {T rounds, E rounds, S rounds, T lanes, E lanes, S lanes}. Diagnostic only. */
-#define RT_N_SCHED 6
+ * served per stage {T rounds, E rounds, S rounds, T lanes, E lanes, S lanes, slab rounds, slab lanes}
+ * (T = traverse inside the grid, E = collision/surface event, S = new direction, slab = everything
+ * outside the grid). Diagnostic only. */
+#define RT_N_SCHED 8
 int rt_get_sched_stats(rt_context* ctx, uint64_t out[RT_N_SCHED]);
 
 /* Device time of the most recent rt_trace launch in milliseconds (HIP events recorded on the

@@ -537,7 +537,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
             fz = iuz > 0.0f ? sl->zface[slab + 1] : sl->zface[slab];
             tx = INFINITY; ty = INFINITY; tz = face_distance(fz, z, iuz);
         }
-        float t_exit = tx; int axis = 0;
+        float t_exit = tx; int axis = gridded ? 0 : 2;           /* a clear-air slab has only its z faces */
         if (ty < t_exit) { t_exit = ty; axis = 1; }
         if (tz < t_exit) { t_exit = tz; axis = 2; }
         const float dn = M > 0.0f ? tau * invM : INFINITY;       /* raytracer_kernels.cu:367 */

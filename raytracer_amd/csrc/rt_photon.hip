@@ -430,7 +430,7 @@ rt_trace_kernel(const TraceArgs a)
                     const float tx = gridded ? face_distance(fx, x, iux) : __builtin_inff();
                     const float ty = gridded ? face_distance(fy, y, iuy) : __builtin_inff();
                     const float tz = face_distance(fz, z, iuz);
-                    float t_exit = tx; int axis = 0;
+                    float t_exit = tx; int axis = gridded ? 0 : 2;      // a clear-air slab has only its z faces
                     if (ty < t_exit) { t_exit = ty; axis = 1; }
                     if (tz < t_exit) { t_exit = tz; axis = 2; }
                     const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff();   // raytracer_kernels.cu:367
@@ -551,19 +551,30 @@ rt_trace_kernel(const TraceArgs a)
 //   g2 {1/ux, 1/uy, 1/uz, w}   w = 1/M of the region (traverse -> collision) or the surface column
 //                              (traverse -> surface event). While a photon waits for stage S the
 //                              group holds {asy, u_mu, u_phi, -}: the reciprocals are dead then.
-//   g3 {ci | cj << 16, ck | slab << 16 | diffuse << 24 | from_cloud << 25, pid_lo, pid_hi | nev << 8}
-enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_DONE = 16 };
-constexpr int kPoolRec = 16;
+//   g3 {ci | cj << 16, ck | slab << 16 | diffuse << 24 | from_cloud << 25}     (8 bytes)
+//   and, in two registers of the lane that owns the slot, {pid_lo, pid_hi | nev << 8}
+//      slab is a signed byte: -1 (below the surface) and nslab (above the domain top) while a photon that
+//      has just left the atmosphere waits for the slab stage
+enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
+constexpr int kPoolRec = 14;
+#ifndef RT_FUSE_LAUNCH
+#define RT_FUSE_LAUNCH 1
+#endif
+#ifndef RT_TH_SLAB
+#define RT_TH_SLAB 16       // photons waiting for the slab stage that get it served ahead of the larger stages
+#endif
 constexpr int kPoolBlock = 64;
 
-// One traverse step of the pool kernel on the photon held in the lane's locals (x, y, z, tau, ux, uy, uz, nstep,
-// ci, cj, ck, slab, diffuse, w11, ns): cross one majorant region or stop at the collision site; IX, IY, IZ are the
-// direction reciprocals. Used by the traverse stage and, fused, at the end of the new-direction stage (a photon
-// that has just been given a direction always traverses next: doing it in the same round saves the slot
-// selection and the LDS round trip of one round per scattering). The region is the aligned cube of 2^L
-// supervoxels per edge around (ci, cj, ck); HIER = false skips the level and the cube arithmetic. Inside a
-// merged region the supervoxel indices follow the position (kept within the region: a coordinate on one of
-// its faces may round to the neighbour's side).
+// One traverse step of the pool kernel INSIDE THE GRIDDED SLAB on the photon held in the lane's locals (x, y,
+// z, tau, ux, uy, uz, nstep, ci, cj, ck, slab, w11, ns): cross one majorant region or stop at the collision site;
+// IX, IY, IZ are the direction reciprocals. Used by the traverse stage and, fused, at the end of the new-
+// direction stage (a photon that has just been given a direction always traverses next: doing it in the same
+// round saves the slot selection and the LDS round trip of one round per scattering). The region is the
+// aligned cube of 2^L supervoxels per edge around (ci, cj, ck); HIER = false skips the level and the cube
+// arithmetic. Inside a merged region the supervoxel indices follow the position (kept within the region: a
+// coordinate on one of its faces may round to the neighbour's side). A photon that leaves the slab through
+// its top or bottom moves its slab index and waits for the slab stage (PS_SLAB), which owns everything
+// outside the grid: the clear-air slabs, the domain top and the surface.
 #define RT_TRAVERSE_STEP(IX, IY, IZ) \
                 if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
                 { \
@@ -574,10 +585,8 @@ constexpr int kPoolBlock = 64;
                 { \
                     ++nstep; \
                     if (STATS) ++ev_step; \
-                    const bool gridded = slab == a.gslab; \
-                    const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab; \
-                    const float2 mm = a.maj[e]; \
-                    const int L = HIER && gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
+                    const float2 mm = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)]; \
+                    const int L = HIER ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
                     if (HIER) \
                     { \
@@ -588,19 +597,10 @@ constexpr int kPoolBlock = 64;
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx; \
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy; \
                     const bool up = (IZ) > 0.0f; \
-                    float fz; \
-                    if (gridded) \
-                    { \
-                        const int cfz = up ? bz1 : bz0; \
-                        fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0); \
-                    } \
-                    else \
-                    { \
-                        const int fi = up ? slab + 1 : slab; \
-                        fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3])); \
-                    } \
-                    const float tx = gridded ? face_distance(fx, x, (IX)) : __builtin_inff(); \
-                    const float ty = gridded ? face_distance(fy, y, (IY)) : __builtin_inff(); \
+                    const int cfz = up ? bz1 : bz0; \
+                    const float fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0); \
+                    const float tx = face_distance(fx, x, (IX)); \
+                    const float ty = face_distance(fy, y, (IY)); \
                     const float tz = face_distance(fz, z, (IZ)); \
                     float t_exit = tx; int axis = 0; \
                     if (ty < t_exit) { t_exit = ty; axis = 1; } \
@@ -609,7 +609,6 @@ constexpr int kPoolBlock = 64;
                     const bool hit = t_exit <= dn; \
                     const float tt = hit ? t_exit : dn; \
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z); \
-                    if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); } \
                     if (HIER && L > 0) \
                     { \
                         ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1); \
@@ -624,7 +623,6 @@ constexpr int kPoolBlock = 64;
                         if (STATS) ++ev_trans; \
                         tau = fma_(-tt, mm.x, tau); \
                         tau = tau > 0.0f ? tau : 0.0f; \
-                        int leave = 0; \
                         if (axis == 0) \
                         { \
                             x = fx; ci = (IX) > 0.0f ? bx1 : bx0 - 1; \
@@ -640,41 +638,87 @@ constexpr int kPoolBlock = 64;
                         else \
                         { \
                             z = fz; \
-                            if (gridded) \
-                            { \
-                                const int nk = up ? bz1 : bz0 - 1; \
-                                if (nk >= 0 && nk < a.nck) ck = nk; else leave = up ? 1 : -1; \
-                            } \
-                            else \
-                                leave = up ? 1 : -1; \
+                            const int nk = up ? bz1 : bz0 - 1; \
+                            if (nk >= 0 && nk < a.nck) ck = nk; \
+                            else { slab += up ? 1 : -1; ns = PS_SLAB; } \
                         } \
-                        if (__builtin_expect(leave != 0, 0)) \
+                    } \
+                }
+
+// One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, nstep, slab, w11, cicj,
+// ck, ns; UX, UY, UZ the direction, IZ the reciprocal of its z component, up = IZ > 0): everything outside the
+// grid. A photon inside a clear-air slab takes its step there (to the slab's top or bottom face, or to a
+// collision site under the slab's own majorant, raytracer_kernels.cu:366-415 with the slab as the only
+// region); a photon that reaches a face -- this way or by leaving the grid in the traverse stage -- arrives at
+// the domain top (raytracer_kernels.cu:487-499), at the surface (:455-460; the albedo draw is stage E) or in
+// the next slab. Used by the slab stage and, fused, at the end of the launch stage (every photon starts with
+// this step when clear air lies above the clouds).
+#define RT_SLAB_STEP(UX, UY, UZ, IZ, DIFFUSE) \
+                bool on_face = true; \
+                ns = PS_SLAB; \
+                if (slab >= 0 && slab < a.nslab) \
+                { \
+                    if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
+                    { \
+                        tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]); \
+                        ns = PS_LAUNCH; \
+                        on_face = false; \
+                    } \
+                    else \
+                    { \
+                        ++nstep; \
+                        if (STATS) ++ev_step; \
+                        const float2 mm = a.maj[a.ncoarse + (uint32_t)slab]; \
+                        const int fi = up ? slab + 1 : slab; \
+                        const float fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3])); \
+                        const float tz = face_distance(fz, z, (IZ)); \
+                        const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff(); \
+                        const bool hit = tz <= dn; \
+                        const float tt = hit ? tz : dn; \
+                        x = fma_((UX), tt, x); y = fma_((UY), tt, y); z = fma_((UZ), tt, z); \
+                        x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); \
+                        w11 = __float_as_uint(mm.y); \
+                        if (!hit) \
                         { \
-                            const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot); \
-                            const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot; \
-                            if (leave > 0 && slab == a.nslab - 1) \
-                            { \
-                                if (STATS) ++ev_toa; \
-                                tally_add(&a.tallies[a.ncol + ij]); \
-                                ns = PS_LAUNCH; \
-                            } \
-                            else if (leave < 0 && slab == 0) \
-                            { \
-                                if (STATS) ++ev_sfc; \
-                                w11 = ij; \
-                                tally_add(&a.tallies[(diffuse ? 3u : 2u) * a.ncol + ij]); \
-                                ns = PS_SURFACE; \
-                            } \
-                            else \
-                            { \
-                                slab += leave; \
-                                if (slab == a.gslab) \
-                                { \
-                                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); \
-                                    ck = leave > 0 ? 0 : a.nck - 1; \
-                                } \
-                            } \
+                            ns = PS_COLLIDE; \
+                            on_face = false; \
                         } \
+                        else \
+                        { \
+                            if (STATS) ++ev_trans; \
+                            tau = fma_(-tt, mm.x, tau); \
+                            tau = tau > 0.0f ? tau : 0.0f; \
+                            z = fz; \
+                            slab += up ? 1 : -1; \
+                        } \
+                    } \
+                } \
+                if (on_face) \
+                { \
+                    if (slab < 0 || slab >= a.nslab) \
+                    { \
+                        const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot); \
+                        const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot; \
+                        if (slab < 0) \
+                        { \
+                            if (STATS) ++ev_sfc; \
+                            w11 = ij; \
+                            tally_add(&a.tallies[((DIFFUSE) ? 3u : 2u) * a.ncol + ij]); \
+                            slab = 0; \
+                            ns = PS_SURFACE; \
+                        } \
+                        else \
+                        { \
+                            if (STATS) ++ev_toa; \
+                            tally_add(&a.tallies[a.ncol + ij]); \
+                            ns = PS_LAUNCH; \
+                        } \
+                    } \
+                    else if (slab == a.gslab) \
+                    { \
+                        cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16); \
+                        ck = up ? 0u : (uint32_t)(a.nck - 1); \
+                        ns = PS_TRAVERSE; \
                     } \
                 }
 
@@ -703,23 +747,31 @@ rt_trace_pool_kernel(const TraceArgs a)
 #pragma unroll
     for (int h = 0; h < kHalves; ++h)
         st[h * 64 + lane] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
-    int n_t = 0, n_e = 0, n_s = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
+    int n_t = 0, n_e = 0, n_s = 0, n_x = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
+    // photon ID words of the slots this lane owns (slot h * 64 + lane): {pid_lo, pid_hi | nev << 8}. Only the
+    // event and launch stages touch them; keeping them out of LDS is what lets 22 waves share a CU
+    uint32_t id_lo[kHalves], id_hn[kHalves];
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h) { id_lo[h] = 0u; id_hn[h] = 0u; }
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
-    uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0;
+    uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0, rounds_x = 0, lanes_x = 0;
 
-    while (n_t + n_e + n_s + n_l > 0)
+    while (n_t + n_e + n_s + n_x + n_l > 0)
     {
         // serve the stage with the most photons waiting (ties: traverse, then event); launches
         // (regeneration) once th_launch slots are free or nothing else is left
         uint32_t cls = (n_t >= n_e && n_t >= n_s) ? 0u : (n_e >= n_s ? 1u : 2u);
-        if (n_l >= a.th_launch || n_t + n_e + n_s == 0)
+        if (n_x >= RT_TH_SLAB || n_x > max(n_t, max(n_e, n_s)))
+            cls = 4u;
+        if (n_l >= a.th_launch || n_t + n_e + n_s + n_x == 0)
             cls = 3u;
 
         // ---- gather up to 64 waiting slots into the lanes ----
         asm volatile("" ::: "memory");
         int found = 0;
+        int srv[kHalves];                // the lane that serves slot h * 64 + lane this round, or -1
 #pragma unroll
         for (int h = 0; h < kHalves; ++h)
         {
@@ -729,6 +781,7 @@ rt_trace_pool_kernel(const TraceArgs a)
             const int rank = found + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (match && rank < 64)
                 sel[rank] = (uint8_t)sidx;
+            srv[h] = (match && rank < 64) ? rank : -1;
             found += __popcll(m);
         }
         asm volatile("" ::: "memory");
@@ -741,7 +794,10 @@ rt_trace_pool_kernel(const TraceArgs a)
         float4* const r4base = reinterpret_cast<float4*>(rec) + slot;
 #define R4(g) r4base[(g) * NS]
 #define RW(k) rec[(((k) >> 2) * NS + slot) * 4 + ((k) & 3)]
+#define RG3(k) rec[3 * NS * 4 + slot * 2 + (k)]
+#define BPERM(LANE, V) (uint32_t)__builtin_amdgcn_ds_bpermute((int)((LANE) << 2), (int)(V))
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
+        uint32_t out_lo = 0u, out_hn = 0u;   // its new ID words (event and launch stages)
 
         if (cls == 2u)
         {
@@ -751,7 +807,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const uint32_t state = st[slot];
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, -}
-                const uint32_t cks = RW(13);
+                const uint32_t cks = RG3(1);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
                 float sp = 0.0f, cp = 0.0f;
                 if (!a.planar)
@@ -821,36 +877,46 @@ rt_trace_pool_kernel(const TraceArgs a)
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
                 const float4 g0 = R4(0);
-                const uint32_t cicj = RW(12);
+                const uint32_t cicj = RG3(0);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
                 uint32_t nstep = __float_as_uint(g1.w);
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
-                const bool diffuse = true;
                 uint32_t w11 = 0u;
-                ns = PS_TRAVERSE;
-                RT_TRAVERSE_STEP(ix, iy, iz)
+                if (slab == a.gslab)
+                {
+                    ns = PS_TRAVERSE;
+                    RT_TRAVERSE_STEP(ix, iy, iz)
+                }
+                else
+                    ns = PS_SLAB;
                 R4(0) = make_float4(x, y, z, tau);
                 R4(1) = make_float4(ux, uy, uz, __uint_as_float(nstep));
                 R4(2) = make_float4(ix, iy, iz, __uint_as_float(w11));
-                RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (1u << 24);
+                RG3(0) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RG3(1) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24);
             }
         }
         else if (cls == 1u)
         {
             if (STATS) { ++rounds_e; lanes_e += n; }
+            // the photon's ID words live in the registers of the lane that owns its slot
+            uint32_t pid_lo = 0u, pn = 0u;
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
+                if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
+            }
             if (active)
             {
                 const uint32_t state = st[slot];
                 uint32_t cell = 0;
                 float inv_m = 0.0f;
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
-                const uint32_t pid_lo = RW(14);
-                const uint32_t pn = RW(15);
                 const uint32_t pid_hi = pn & 0xffu;
                 uint32_t nev = pn >> 8;
-                const uint32_t cks = RW(13);
+                const uint32_t cks = RG3(1);
                 const uint32_t w11 = RW(11);
                 if (state == PS_COLLIDE)
                 {
@@ -871,6 +937,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 asm volatile("" : "+s"(rk0), "+s"(rk1));
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
                 ++nev;
+                out_hn = pid_hi | (nev << 8);
                 float tau_new = free_path_tau(u01(w.y));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
 
@@ -880,9 +947,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                     if (STATS) ++ev_coll;
                     const float rr = u01(w.x);
                     const float p_real = kt * inv_m;
-                    ns = PS_TRAVERSE;
+                    ns = (int)((cks >> 16) & 0xffu) == a.gslab ? PS_TRAVERSE : PS_SLAB;
                     RW(3) = __float_as_uint(tau_new);
-                    RW(15) = pid_hi | (nev << 8);
                     if (rr < p_real)
                     {
                         if (STATS) ++ev_real;
@@ -892,7 +958,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                             const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
                             if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
                             R4(2) = make_float4(cr.z, u01(w.z), u01(w.w), 0.0f);
-                            RW(13) = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
+                            RG3(1) = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
                             ns = PS_SCATTER;
                         }
                         else
@@ -908,7 +974,6 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                 {
                     // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    RW(15) = pid_hi | (nev << 8);
                     if (u01(w.x) <= a.launch->albedo)
                     {
                         tally_add(&a.tallies[4u * a.ncol + cell]);
@@ -978,21 +1043,35 @@ rt_trace_pool_kernel(const TraceArgs a)
                     x = fma_(u01(w.x), dx, (float)ic * dx);
                     y = fma_(u01(w.y), dy, (float)jc * dy);
                 }
-                const int slab = a.nslab - 1;
-                int ci = 0, cj = 0, ck = 0;
-                if (slab == a.gslab)
-                {
-                    ci = cell_of(x, a.inv_hx, a.nci); cj = cell_of(y, a.inv_hy, a.ncj); ck = a.nck - 1;
-                }
-                R4(0) = make_float4(x, y, lb->ztop, tau_new);
-                R4(1) = make_float4(lb->sun_x, lb->sun_y, lb->sun_z, __uint_as_float(0u));
-                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, lb->inv_sun_z, 0.0f);
-                R4(3) = make_float4(__uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)),
-                                    __uint_as_float((uint32_t)ck | ((uint32_t)slab << 16)),
-                                    __uint_as_float(pid_lo), __uint_as_float(pid_hi | (1u << 8)));
                 const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
                 toa_col = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
-                ns = PS_TRAVERSE;
+                int slab = a.nslab - 1;
+                float z = lb->ztop, tau = tau_new;
+                const float sun_x = lb->sun_x, sun_y = lb->sun_y, sun_z = lb->sun_z, iz = lb->inv_sun_z;
+                uint32_t nstep = 0u, w11 = 0u, cicj = 0u, ck = 0u;
+                if (slab == a.gslab)
+                {
+                    cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16);
+                    ck = (uint32_t)(a.nck - 1);
+                    ns = PS_TRAVERSE;
+                }
+                else
+                {
+                    // the first step, through the clear air above the clouds, at once
+#if RT_FUSE_LAUNCH
+                    const bool up = false;
+                    RT_SLAB_STEP(sun_x, sun_y, sun_z, iz, false)
+#else
+                    ns = PS_SLAB;
+#endif
+                }
+                R4(0) = make_float4(x, y, z, tau);
+                R4(1) = make_float4(sun_x, sun_y, sun_z, __uint_as_float(nstep));
+                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz, __uint_as_float(w11));
+                RG3(0) = cicj;
+                RG3(1) = ck | (((uint32_t)slab & 0xffu) << 16);
+                out_lo = pid_lo;
+                out_hn = pid_hi | (1u << 8);
             }
             // TOA-down tally. Stratified launch puts runs of consecutive lanes into one column: the
             // first lane of a run adds the run's length (one atomic per run instead of one per photon).
@@ -1013,6 +1092,30 @@ rt_trace_pool_kernel(const TraceArgs a)
             wave_next += adv;
             wave_left -= adv;
         }
+        else if (__builtin_expect(cls == 4u, 0))
+        {
+            // ---- slab stage: everything outside the grid ----
+            if (STATS) { ++rounds_x; lanes_x += n; }
+            if (active)
+            {
+                const float4 g0 = R4(0);
+                const float4 g1 = R4(1);
+                const float iz = __uint_as_float(RW(10));
+                const uint32_t cks = RG3(1);
+                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
+                uint32_t nstep = __float_as_uint(g1.w);
+                int slab = (int)(int8_t)((cks >> 16) & 0xffu);
+                const bool up = iz > 0.0f;
+                uint32_t w11 = 0u, cicj = 0u, ck = cks & 0xffffu;
+                RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
+                R4(0) = make_float4(x, y, z, tau);
+                RW(7) = nstep;
+                RW(11) = w11;
+                if (ns == PS_TRAVERSE)
+                    RG3(0) = cicj;
+                RG3(1) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
+            }
+        }
         else
         {
             if (STATS) { ++rounds_t; lanes_t += n; }
@@ -1021,34 +1124,56 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float4 g0 = R4(0);
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);
-                const uint32_t cicj = RW(12), cks = RW(13);
+                const uint32_t cicj = RG3(0), cks = RG3(1);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
                 const float ux = g1.x, uy = g1.y, uz = g1.z;
                 uint32_t nstep = __float_as_uint(g1.w);
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
-                const bool diffuse = (cks >> 24) & 1u;
                 ns = PS_TRAVERSE;
                 uint32_t w11 = RW(11);
                 RT_TRAVERSE_STEP(g2.x, g2.y, g2.z)
                 R4(0) = make_float4(x, y, z, tau);
                 RW(7) = nstep;
                 RW(11) = w11;
-                RW(12) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RW(13) = (uint32_t)ck | ((uint32_t)slab << 16) | (diffuse ? 1u << 24 : 0u);
+                RG3(0) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RG3(1) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
             }
         }
 
 #undef R4
 #undef RW
+#undef RG3
+        // ---- the owners of the served slots take the new ID words from the lanes that served them ----
+        if (cls == 1u || cls == 3u)
+        {
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t hn = BPERM((uint32_t)srv[h] & 63u, out_hn);
+                if (srv[h] >= 0) id_hn[h] = hn;
+            }
+            if (cls == 3u)
+            {
+#pragma unroll
+                for (int h = 0; h < kHalves; ++h)
+                {
+                    const uint32_t lo = BPERM((uint32_t)srv[h] & 63u, out_lo);
+                    if (srv[h] >= 0) id_lo[h] = lo;
+                }
+            }
+        }
+#undef BPERM
         // ---- publish the new states and update the stage counts ----
         if (active)
             st[slot] = (uint8_t)ns;
-        const uint32_t ncls = active ? (ns >> 2) : 4u;
+        const uint32_t ncls = active ? (ns >> 2) : 5u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
-                  d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u));
-        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else if (cls == 2u) n_s -= n; else n_l -= n;
-        n_t += d_t; n_e += d_e; n_s += d_s; n_l += d_l;
+                  d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
+                  d_x = __popcll(__ballot(ncls == 4u));
+        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else if (cls == 2u) n_s -= n;
+        else if (cls == 3u) n_l -= n; else n_x -= n;
+        n_t += d_t; n_e += d_e; n_s += d_s; n_l += d_l; n_x += d_x;
     }
 
     if (STATS)
@@ -1061,9 +1186,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                                        __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0)
         {
-            const uint32_t sch[6] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s};
+            const uint32_t sch[8] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s, rounds_x, lanes_x};
 #pragma unroll
-            for (int e = 0; e < 6; ++e)
+            for (int e = 0; e < 8; ++e)
                 __hip_atomic_fetch_add(&(a.cursor - kCursorWord)[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }

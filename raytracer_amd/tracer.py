@@ -188,10 +188,10 @@ class PhotonTracer:
 
     def sched_stats(self):
         """Rounds and served lanes per stage of the wave scheduler (stats launches only)."""
-        v = np.zeros(6, dtype=np.uint64)
+        v = np.zeros(8, dtype=np.uint64)
         _check(self.lib.rt_get_sched_stats(self._h, v.ctypes.data_as(C.POINTER(C.c_uint64))))
         r = [int(x) for x in v]
-        return {"rounds": dict(T=r[0], E=r[1], S=r[2]), "lanes": dict(T=r[3], E=r[4], S=r[5])}
+        return {"rounds": dict(T=r[0], E=r[1], S=r[2], slab=r[6]), "lanes": dict(T=r[3], E=r[4], S=r[5], slab=r[7])}
 
     def slabs(self):
         s = SlabInfo()
