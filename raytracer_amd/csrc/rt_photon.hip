@@ -544,19 +544,21 @@ rt_trace_kernel(const TraceArgs a)
 // resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
 // One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
 //
-// LDS per wave: NS records of four 16-byte groups (stored group-major), NS state bytes and a
+// LDS per wave: NS records of three 16-byte groups (stored group-major), NS state bytes and a
 // 64-entry selection list (bytes):
-//   g0 {x, y, z, tau}
-//   g1 {ux, uy, uz, nstep}
-//   g2 {1/ux, 1/uy, 1/uz, w}   w = 1/M of the region (traverse -> collision) or the surface column
-//                              (traverse -> surface event). While a photon waits for stage S the
-//                              group holds {asy, u_mu, u_phi, -}: the reciprocals are dead then.
-//   g3 {ci | cj << 16, ck | slab << 16 | diffuse << 24 | from_cloud << 25}     (8 bytes)
-//   and, in two registers of the lane that owns the slot, {pid_lo, pid_hi | nev << 8}
-//      slab is a signed byte: -1 (below the surface) and nslab (above the domain top) while a photon that
-//      has just left the atmosphere waits for the slab stage
+//   g0 {x, y, z, tau}          tau holds 1/M of the region while the photon waits for its collision event
+//                              (the event stage draws the next tau before anything reads it)
+//   g1 {ux, uy, uz, ci | cj << 16}
+//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25}
+//                              While a photon waits for stage S the first three hold {asy, u_mu, u_phi}: the
+//                              reciprocals are dead then. slab is a signed byte: -1 (below the surface) and
+//                              nslab (above the domain top) while a photon that has just left the atmosphere
+//                              waits for the slab stage
+// and, in three registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
+// that serves it, taken back by the owner at the end of the round), {pid_lo, pid_hi | nev << 8, nstep}.
+// 6336 bytes per wave at NS = 128: 25 waves share a CU's 160 KB (19 with the full 64-byte record in LDS).
 enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
-constexpr int kPoolRec = 14;
+constexpr int kPoolRec = 12;
 #ifndef RT_FUSE_LAUNCH
 #define RT_FUSE_LAUNCH 1
 #endif
@@ -566,7 +568,8 @@ constexpr int kPoolRec = 14;
 constexpr int kPoolBlock = 64;
 
 // One traverse step of the pool kernel INSIDE THE GRIDDED SLAB on the photon held in the lane's locals (x, y,
-// z, tau, ux, uy, uz, nstep, ci, cj, ck, slab, w11, ns): cross one majorant region or stop at the collision site;
+// z, tau, ux, uy, uz, nstep, ci, cj, ck, slab, ns): cross one majorant region or stop at the collision site
+// (tau then carries 1/M of the region to the event stage, which draws the next tau anyway);
 // IX, IY, IZ are the direction reciprocals. Used by the traverse stage and, fused, at the end of the new-
 // direction stage (a photon that has just been given a direction always traverses next: doing it in the same
 // round saves the slot selection and the LDS round trip of one round per scattering). The region is the
@@ -615,9 +618,11 @@ constexpr int kPoolBlock = 64;
                         cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1); \
                         ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1); \
                     } \
-                    w11 = __float_as_uint(mm.y); \
                     if (!hit) \
+                    { \
                         ns = PS_COLLIDE; \
+                        tau = mm.y; \
+                    } \
                     else \
                     { \
                         if (STATS) ++ev_trans; \
@@ -645,7 +650,7 @@ constexpr int kPoolBlock = 64;
                     } \
                 }
 
-// One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, nstep, slab, w11, cicj,
+// One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, nstep, slab, cicj,
 // ck, ns; UX, UY, UZ the direction, IZ the reciprocal of its z component, up = IZ > 0): everything outside the
 // grid. A photon inside a clear-air slab takes its step there (to the slab's top or bottom face, or to a
 // collision site under the slab's own majorant, raytracer_kernels.cu:366-415 with the slab as the only
@@ -677,10 +682,10 @@ constexpr int kPoolBlock = 64;
                         const float tt = hit ? tz : dn; \
                         x = fma_((UX), tt, x); y = fma_((UY), tt, y); z = fma_((UZ), tt, z); \
                         x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); \
-                        w11 = __float_as_uint(mm.y); \
                         if (!hit) \
                         { \
                             ns = PS_COLLIDE; \
+                            tau = mm.y; \
                             on_face = false; \
                         } \
                         else \
@@ -702,7 +707,6 @@ constexpr int kPoolBlock = 64;
                         if (slab < 0) \
                         { \
                             if (STATS) ++ev_sfc; \
-                            w11 = ij; \
                             tally_add(&a.tallies[((DIFFUSE) ? 3u : 2u) * a.ncol + ij]); \
                             slab = 0; \
                             ns = PS_SURFACE; \
@@ -750,9 +754,9 @@ rt_trace_pool_kernel(const TraceArgs a)
     int n_t = 0, n_e = 0, n_s = 0, n_x = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
     // photon ID words of the slots this lane owns (slot h * 64 + lane): {pid_lo, pid_hi | nev << 8}. Only the
     // event and launch stages touch them; keeping them out of LDS is what lets 22 waves share a CU
-    uint32_t id_lo[kHalves], id_hn[kHalves];
+    uint32_t id_lo[kHalves], id_hn[kHalves], nst[kHalves];
 #pragma unroll
-    for (int h = 0; h < kHalves; ++h) { id_lo[h] = 0u; id_hn[h] = 0u; }
+    for (int h = 0; h < kHalves; ++h) { id_lo[h] = 0u; id_hn[h] = 0u; nst[h] = 0u; }
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
@@ -794,10 +798,19 @@ rt_trace_pool_kernel(const TraceArgs a)
         float4* const r4base = reinterpret_cast<float4*>(rec) + slot;
 #define R4(g) r4base[(g) * NS]
 #define RW(k) rec[(((k) >> 2) * NS + slot) * 4 + ((k) & 3)]
-#define RG3(k) rec[3 * NS * 4 + slot * 2 + (k)]
 #define BPERM(LANE, V) (uint32_t)__builtin_amdgcn_ds_bpermute((int)((LANE) << 2), (int)(V))
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
         uint32_t out_lo = 0u, out_hn = 0u;   // its new ID words (event and launch stages)
+        uint32_t nstep = 0u;             // its step count (every stage but the event stage)
+        if (cls != 1u && cls != 3u)
+        {
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t v = BPERM(slot & 63u, nst[h]);
+                if ((slot >> 6) == (uint32_t)h) nstep = v;
+            }
+        }
 
         if (cls == 2u)
         {
@@ -806,8 +819,8 @@ rt_trace_pool_kernel(const TraceArgs a)
             {
                 const uint32_t state = st[slot];
                 const float4 g1 = R4(1);
-                const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, -}
-                const uint32_t cks = RG3(1);
+                const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, cks}
+                const uint32_t cks = __float_as_uint(g2.w);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
                 float sp = 0.0f, cp = 0.0f;
                 if (!a.planar)
@@ -877,12 +890,10 @@ rt_trace_pool_kernel(const TraceArgs a)
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
                 const float4 g0 = R4(0);
-                const uint32_t cicj = RG3(0);
+                const uint32_t cicj = __float_as_uint(g1.w);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                uint32_t nstep = __float_as_uint(g1.w);
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
-                uint32_t w11 = 0u;
                 if (slab == a.gslab)
                 {
                     ns = PS_TRAVERSE;
@@ -891,10 +902,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                     ns = PS_SLAB;
                 R4(0) = make_float4(x, y, z, tau);
-                R4(1) = make_float4(ux, uy, uz, __uint_as_float(nstep));
-                R4(2) = make_float4(ix, iy, iz, __uint_as_float(w11));
-                RG3(0) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RG3(1) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24);
+                R4(1) = make_float4(ux, uy, uz, __uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)));
+                R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24)));
             }
         }
         else if (cls == 1u)
@@ -916,19 +925,20 @@ rt_trace_pool_kernel(const TraceArgs a)
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t pid_hi = pn & 0xffu;
                 uint32_t nev = pn >> 8;
-                const uint32_t cks = RG3(1);
-                const uint32_t w11 = RW(11);
-                if (state == PS_COLLIDE)
+                const uint32_t cks = RW(11);
                 {
+                    // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
+                    // dead until the draw below); a photon on the surface has its column from (x, y)
                     const float4 g0 = R4(0);
-                    inv_m = __uint_as_float(w11);
                     const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
-                    const int k = cell_of(g0.z, a.inv_dz, a.ktot);
-                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot + (uint32_t)k * a.ncol;
-                    cr = a.cells[cell];
+                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                    if (state == PS_COLLIDE)
+                    {
+                        inv_m = g0.w;
+                        cell += (uint32_t)cell_of(g0.z, a.inv_dz, a.ktot) * a.ncol;
+                        cr = a.cells[cell];
+                    }
                 }
-                else
-                    cell = w11;          // surface column stored by the traverse stage
                 const float kt = cr.x;
                 // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
                 // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
@@ -957,8 +967,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                         {
                             const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
                             if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w), 0.0f);
-                            RG3(1) = (cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u);
+                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w),
+                                                __uint_as_float((cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u)));
                             ns = PS_SCATTER;
                         }
                         else
@@ -1048,7 +1058,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 int slab = a.nslab - 1;
                 float z = lb->ztop, tau = tau_new;
                 const float sun_x = lb->sun_x, sun_y = lb->sun_y, sun_z = lb->sun_z, iz = lb->inv_sun_z;
-                uint32_t nstep = 0u, w11 = 0u, cicj = 0u, ck = 0u;
+                uint32_t cicj = 0u, ck = 0u;
                 if (slab == a.gslab)
                 {
                     cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16);
@@ -1066,10 +1076,8 @@ rt_trace_pool_kernel(const TraceArgs a)
 #endif
                 }
                 R4(0) = make_float4(x, y, z, tau);
-                R4(1) = make_float4(sun_x, sun_y, sun_z, __uint_as_float(nstep));
-                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz, __uint_as_float(w11));
-                RG3(0) = cicj;
-                RG3(1) = ck | (((uint32_t)slab & 0xffu) << 16);
+                R4(1) = make_float4(sun_x, sun_y, sun_z, __uint_as_float(cicj));
+                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz, __uint_as_float(ck | (((uint32_t)slab & 0xffu) << 16)));
                 out_lo = pid_lo;
                 out_hn = pid_hi | (1u << 8);
             }
@@ -1101,19 +1109,16 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float4 g0 = R4(0);
                 const float4 g1 = R4(1);
                 const float iz = __uint_as_float(RW(10));
-                const uint32_t cks = RG3(1);
+                const uint32_t cks = RW(11);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                uint32_t nstep = __float_as_uint(g1.w);
                 int slab = (int)(int8_t)((cks >> 16) & 0xffu);
                 const bool up = iz > 0.0f;
-                uint32_t w11 = 0u, cicj = 0u, ck = cks & 0xffffu;
+                uint32_t cicj = 0u, ck = cks & 0xffffu;
                 RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
                 R4(0) = make_float4(x, y, z, tau);
-                RW(7) = nstep;
-                RW(11) = w11;
                 if (ns == PS_TRAVERSE)
-                    RG3(0) = cicj;
-                RG3(1) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
+                    RW(7) = cicj;
+                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
             }
         }
         else
@@ -1124,27 +1129,31 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float4 g0 = R4(0);
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);
-                const uint32_t cicj = RG3(0), cks = RG3(1);
+                const uint32_t cicj = __float_as_uint(g1.w), cks = __float_as_uint(g2.w);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
                 const float ux = g1.x, uy = g1.y, uz = g1.z;
-                uint32_t nstep = __float_as_uint(g1.w);
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
                 ns = PS_TRAVERSE;
-                uint32_t w11 = RW(11);
                 RT_TRAVERSE_STEP(g2.x, g2.y, g2.z)
                 R4(0) = make_float4(x, y, z, tau);
-                RW(7) = nstep;
-                RW(11) = w11;
-                RG3(0) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RG3(1) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
+                RW(7) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
             }
         }
 
 #undef R4
 #undef RW
-#undef RG3
         // ---- the owners of the served slots take the new ID words from the lanes that served them ----
+        if (cls != 1u)
+        {
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t v = BPERM((uint32_t)srv[h] & 63u, nstep);
+                if (srv[h] >= 0) nst[h] = v;
+            }
+        }
         if (cls == 1u || cls == 3u)
         {
 #pragma unroll
