@@ -578,7 +578,7 @@ constexpr int kPoolBlock = 64;
 // coordinate on one of its faces may round to the neighbour's side). A photon that leaves the slab through
 // its top or bottom moves its slab index and waits for the slab stage (PS_SLAB), which owns everything
 // outside the grid: the clear-air slabs, the domain top and the surface.
-#define RT_TRAVERSE_STEP(IX, IY, IZ) \
+#define RT_TRAVERSE_STEP(IX, IY, IZ, MM) \
                 if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
                 { \
                     tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]); \
@@ -588,7 +588,7 @@ constexpr int kPoolBlock = 64;
                 { \
                     ++nstep; \
                     if (STATS) ++ev_step; \
-                    const float2 mm = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)]; \
+                    const float2 mm = (MM); \
                     const int L = HIER ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
                     if (HIER) \
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(kPoolBlock)
 rt_trace_pool_kernel(const TraceArgs a)
 {
     using namespace rt;
-    static_assert(NS % 32 == 0 && NS >= 64 && NS <= 256, "pool size");
+    static_assert(NS % 16 == 0 && NS >= 64 && NS <= 256, "pool size");
     constexpr int kHalves = (NS + 63) / 64;
     __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + kHalves * 16 + 16];
 
@@ -821,6 +821,14 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, cks}
                 const uint32_t cks = __float_as_uint(g2.w);
+                // the majorant of the photon's region for the traverse step at the end of this stage: asked for
+                // now, so that the scattering arithmetic runs while the gather is under way
+                const uint32_t cicj = __float_as_uint(g1.w);
+                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
+                int slab = (int)((cks >> 16) & 0xffu);
+                float2 mm_pre = make_float2(0.0f, 0.0f);
+                if (slab == a.gslab)
+                    mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
                 float ux = g1.x, uy = g1.y, uz = g1.z;
                 float sp = 0.0f, cp = 0.0f;
                 if (!a.planar)
@@ -890,14 +898,11 @@ rt_trace_pool_kernel(const TraceArgs a)
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
                 const float4 g0 = R4(0);
-                const uint32_t cicj = __float_as_uint(g1.w);
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
-                int slab = (int)((cks >> 16) & 0xffu);
                 if (slab == a.gslab)
                 {
                     ns = PS_TRAVERSE;
-                    RT_TRAVERSE_STEP(ix, iy, iz)
+                    RT_TRAVERSE_STEP(ix, iy, iz, mm_pre)
                 }
                 else
                     ns = PS_SLAB;
@@ -1135,7 +1140,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
                 ns = PS_TRAVERSE;
-                RT_TRAVERSE_STEP(g2.x, g2.y, g2.z)
+                RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
                 R4(0) = make_float4(x, y, z, tau);
                 RW(7) = (uint32_t)ci | ((uint32_t)cj << 16);
                 RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
