@@ -213,9 +213,14 @@ int rt_last_trace_ms(rt_context* ctx, float* ms);
 /* Test hook: Philox4x32-10 on the device, n counter blocks (4 words each) under one key. */
 int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint32_t key[2], uint32_t* out);
 
-/* Test hook: evaluates the device math (0 = log, 1 = cbrt, 2 = sin(2*pi*x), 3 = cos(2*pi*x)) on n
+/* Test hook: evaluates the device math (0 = log, 1 = x^(-1/3), 2 = sin(2*pi*x), 3 = cos(2*pi*x)) on n
  * host floats. */
 int rt_selftest_math(int device_id, int which, const float* in, size_t n, float* out);
+
+/* Test hook: the device's short sqrt (which = 0) or reciprocal (which = 1) against the compiler's IEEE
+ * sqrtf / division on the `count` consecutive float bit patterns from first_bits on; out[0] = number of
+ * patterns whose results differ in any bit, out[1] = the lowest such pattern (~0 if none). */
+int rt_selftest_exact(int device_id, int which, uint32_t first_bits, uint64_t count, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -137,25 +137,28 @@ void oracle_sincos2pi(float u, float* s_out, float* c_out)
     }
 }
 
-/* cube root of a positive normal float: bit-shift seed + three Halley steps */
-float oracle_cbrtf(float x)
+/* x^(-1/3) of a positive normal float: bit-shift seed + three division-free Newton steps y <- y (4 - x y^3) / 3 */
+float oracle_inv_cbrtf(float x)
 {
-    float t = u2f(f2u(x) / 3u + 709958130u);
+    float y = u2f(0x54a2fa8cu - f2u(x) / 3u);
+    const float x3 = x * 0.3333333432674408f;
     for (int it = 0; it < 3; ++it)
     {
-        const float t3 = t * t * t;
-        t = t * (fmaf(2.0f, x, t3) / fmaf(2.0f, t3, x));
+        const float y3 = (y * y) * y;
+        y = y * fmaf(-x3, y3, 1.3333333730697632f);
     }
-    return t;
+    return y;
 }
 
-/* raytracer_kernels.cu:145-152 with pow(., 1/3) as the cube root above */
+/* raytracer_kernels.cu:145-152: mu = u - 1/u, u = pow(v, 1/3), v = -q + sqrt(q^2 + 1), written with
+ * y = v^(-1/3) (u = v y^2, 1/u = y): mu = y (v y - 1) */
 static inline float rayleigh_mu(float r)
 {
     const float q = fmaf(4.0f, r, -2.0f);
     const float d = fmaf(q, q, 1.0f);
-    const float u = oracle_cbrtf(-q + sqrtf(d));
-    return u - 1.0f / u;
+    const float v = -q + sqrtf(d);
+    const float y = oracle_inv_cbrtf(v);
+    return y * fmaf(v, y, -1.0f);
 }
 
 /* raytracer_kernels.cu:155-162. The reference divides by g; |g| < 1e-3 takes the g -> 0 limit

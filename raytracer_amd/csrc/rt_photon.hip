@@ -132,6 +132,8 @@ __device__ __forceinline__ void tally_add(unsigned long long* p, unsigned long l
 // so that (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component.
 __device__ __forceinline__ float dir_reciprocal(float u)
 {
+    if (__builtin_expect(__builtin_fabsf(u) >= 0x1p-100f, 1))
+        return rt::rt_rcp(u);            // == 1.0f / u there, and within +-2^100: nothing to clamp
     return __builtin_fminf(__builtin_fmaxf(1.0f / u, -3.402823466e+38f), 3.402823466e+38f);
 }
 
@@ -843,7 +845,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     {
                         const bool from_cloud = (cks >> 25) & 1u;
                         const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
-                        const float sn2 = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f), 0.0f));
+                        const float sn2 = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f), 0.0f));
                         const float ssn = plus ? sn2 : -sn2;
                         const float nx = fma_(mu, ux, ssn * uz);
                         const float nz = fma_(mu, uz, -(ssn * ux));
@@ -851,9 +853,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                     }
                     else
                     {
-                        const float mu = __builtin_sqrtf(g2.y);
+                        const float mu = rt_sqrt(g2.y);
                         ux = plus ? mu : -mu;
-                        uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f));
+                        uz = rt_sqrt(fma_(-mu, mu, 1.0f));
                     }
                     uy = 0.0f;
                 }
@@ -862,7 +864,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     // phase function + rotation, raytracer_kernels.cu:520-548
                     const bool from_cloud = (cks >> 25) & 1u;
                     const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
-                    const float sn = __builtin_sqrtf(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
+                    const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
                     float ax = 0.0f, ay = 0.0f, az = 0.0f;
                     const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
                     if (fx < fy)
@@ -877,7 +879,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
                                                  : fma_(az, az, fma_(ay, uy, ax * ux));
                     float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
-                    const float inv_len = 1.0f / __builtin_sqrtf(fma_(oz, oz, fma_(oy, oy, ox * ox)));
+                    const float inv_len = rt_rcp(rt_sqrt(fma_(oz, oz, fma_(oy, oy, ox * ox))));
                     ox *= inv_len; oy *= inv_len; oz *= inv_len;
                     const float bx = fma_(uy, oz, -(uz * oy));
                     const float by = fma_(uz, ox, -(ux * oz));
@@ -890,10 +892,10 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                 {
                     // Lambertian reflection, raytracer_kernels.cu:467-473
-                    const float mu = __builtin_sqrtf(g2.y);
+                    const float mu = rt_sqrt(g2.y);
                     ux = mu * sp;
                     uy = mu * cp;
-                    uz = __builtin_sqrtf(fma_(-mu, mu, 1.0f) + RT_EPS);
+                    uz = rt_sqrt(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
@@ -1322,11 +1324,28 @@ __global__ void rt_selftest_math_kernel(int which, const float* in, size_t n, fl
         switch (which)
         {
             case 0: out[t] = rt::rt_log(v); break;
-            case 1: out[t] = rt::rt_cbrt(v); break;
+            case 1: out[t] = rt::rt_inv_cbrt(v); break;
             case 2: rt::rt_sincos2pi(v, s, c); out[t] = s; break;
             case 3: rt::rt_sincos2pi(v, s, c); out[t] = c; break;
             case 4: out[t] = rt::rayleigh_mu(v); break;
             default: out[t] = rt::henyey_mu(0.85f, v); break;
+        }
+    }
+}
+// rt_sqrt / rt_rcp against the compiler's IEEE sqrtf / division over a range of bit patterns
+__global__ void rt_selftest_exact_kernel(int which, uint32_t first, unsigned long long count, unsigned long long* out)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+    {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        const float want = which == 0 ? __builtin_sqrtf(x) : 1.0f / x;
+        const float got = which == 0 ? rt::rt_sqrt(x) : rt::rt_rcp(x);
+        if (__float_as_uint(want) != __float_as_uint(got))
+        {
+            atomicAdd(&out[0], 1ull);
+            atomicMin(&out[1], (unsigned long long)bits);
         }
     }
 }
@@ -2072,6 +2091,26 @@ int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint3
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpy(out, d_out, 16 * n, hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out);
+    return RT_OK;
+}
+
+int rt_selftest_exact(int device_id, int which, uint32_t first_bits, uint64_t count, uint64_t out[2])
+{
+    if (!out || which < 0 || which > 1) return fail(RT_ERR_ARG, "rt_selftest_exact: bad argument");
+    if (count > (1ull << 32) - first_bits) return fail(RT_ERR_ARG, "rt_selftest_exact: range beyond 2^32 bit patterns");
+    RT_HIP(hipSetDevice(device_id));
+    unsigned long long* d_out = nullptr;
+    const unsigned long long init[2] = {0ull, ~0ull};
+    RT_HIP(hipMalloc(&d_out, sizeof(init)));
+    RT_HIP(hipMemcpy(d_out, init, sizeof(init), hipMemcpyHostToDevice));
+    if (count > 0)
+        hipLaunchKernelGGL(rt_selftest_exact_kernel, dim3(256 * 16), dim3(256), 0, 0, which, first_bits,
+                           (unsigned long long)count, d_out);
+    RT_HIP(hipGetLastError());
+    unsigned long long res[2];
+    RT_HIP(hipMemcpy(res, d_out, sizeof(res), hipMemcpyDeviceToHost));
+    (void)hipFree(d_out);
+    out[0] = res[0]; out[1] = res[1];
     return RT_OK;
 }
 

@@ -72,6 +72,7 @@ def load_library():
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "rt_selftest_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "rt_selftest_math": (C.c_int, [C.c_int, C.c_int, f32p, C.c_size_t, f32p]),
+        "rt_selftest_exact": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint64, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -68,8 +68,8 @@ def lib():
         _lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         _lib.oracle_logf.restype = C.c_float
         _lib.oracle_logf.argtypes = [C.c_float]
-        _lib.oracle_cbrtf.restype = C.c_float
-        _lib.oracle_cbrtf.argtypes = [C.c_float]
+        _lib.oracle_inv_cbrtf.restype = C.c_float
+        _lib.oracle_inv_cbrtf.argtypes = [C.c_float]
         _lib.oracle_rayleigh_mu.restype = C.c_float
         _lib.oracle_rayleigh_mu.argtypes = [C.c_float]
         _lib.oracle_henyey_mu.restype = C.c_float

@@ -54,6 +54,20 @@ def test_philox_device_matches_known_answers_and_oracle(rt):
         assert list(w) == [int(v) for v in out[r]]
 
 
+def test_short_sqrt_and_reciprocal_are_ieee_exact_on_their_domains(rt):
+    """rt_sqrt / rt_rcp (hardware estimate + fused fix-up, rt_device.hip.h) against the compiler's IEEE sqrtf and
+    division on EVERY float bit pattern of the ranges the tracer feeds them: that is what lets the oracle keep
+    plain sqrtf() and 1.0f / x."""
+    lib = rt.load_library()
+    out = (C.c_uint64 * 2)()
+    lo, hi = 0x0F800000, 0x6F800000           # 2^-96 .. 2^96
+    rlo, rhi = 0x0D800000, 0x71800000         # 2^-100 .. 2^100
+    for which, first, count in ((0, 0, 1), (0, lo, hi - lo + 1), (1, rlo, rhi - rlo + 1),
+                                (1, 0x80000000 | rlo, rhi - rlo + 1)):
+        assert lib.rt_selftest_exact(0, which, first, count, out) == 0, lib.rt_last_error()
+        assert out[0] == 0, f"fn {which}: {out[0]} of {count} patterns differ, the first is 0x{out[1]:08x}"
+
+
 def test_device_math_is_bit_identical_to_oracle(rt):
     lib = rt.load_library()
     ol = O.lib()
@@ -72,7 +86,7 @@ def test_device_math_is_bit_identical_to_oracle(rt):
             if which == 0:
                 want[i] = ol.oracle_logf(float(v))
             elif which == 1:
-                want[i] = ol.oracle_cbrtf(float(v))
+                want[i] = ol.oracle_inv_cbrtf(float(v))
             else:
                 ol.oracle_sincos2pi(float(v), C.byref(s), C.byref(c))
                 want[i] = s.value if which == 2 else c.value

@@ -37,7 +37,7 @@ def test_math_accuracy():
         L.oracle_sincos2pi(float(v), C.byref(s), C.byref(c))
         assert abs(s.value - np.sin(2 * np.pi * float(v))) < 5e-7 and abs(c.value - np.cos(2 * np.pi * float(v))) < 5e-7
     for v in np.linspace(0.2, 4.3, 2001, dtype=np.float32):
-        assert abs(L.oracle_cbrtf(float(v)) - float(v) ** (1 / 3)) < 3e-7 * float(v) ** (1 / 3) + 1e-7
+        assert abs(L.oracle_inv_cbrtf(float(v)) - float(v) ** (-1 / 3)) < 3e-7 * float(v) ** (-1 / 3)
 
 
 def test_sampler_moments():
