@@ -66,6 +66,10 @@ def test_short_sqrt_and_reciprocal_are_ieee_exact_on_their_domains(rt):
                                 (1, 0x80000000 | rlo, rhi - rlo + 1)):
         assert lib.rt_selftest_exact(0, which, first, count, out) == 0, lib.rt_last_error()
         assert out[0] == 0, f"fn {which}: {out[0]} of {count} patterns differ, the first is 0x{out[1]:08x}"
+    # the hook itself: outside the domain the short forms do differ (denormal results), and bad arguments are refused
+    assert lib.rt_selftest_exact(0, 1, 0x7E000000, 0x01000000, out) == 0 and out[0] > 0 and out[1] >= 0x7E000000
+    assert lib.rt_selftest_exact(0, 2, 0, 1, out) != 0 and b"rt_selftest_exact" in lib.rt_last_error()
+    assert lib.rt_selftest_exact(0, 0, 0xFFFFFFFF, 2, out) != 0
 
 
 def test_device_math_is_bit_identical_to_oracle(rt):
