@@ -51,6 +51,17 @@ int fail(int code, const char* fmt, ...)
             return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// device allocation of a test hook: freed on every way out of the function, error returns included
+template <typename T>
+struct HookBuffer
+{
+    T* p = nullptr;
+    HookBuffer() = default;
+    HookBuffer(const HookBuffer&) = delete;
+    HookBuffer& operator=(const HookBuffer&) = delete;
+    ~HookBuffer() { if (p) (void)hipFree(p); }
+};
+
 constexpr int kBlock = 256;
 // device words behind rt_context::d_events: RT_N_EVENTS counters, RT_N_SCHED scheduler statistics and,
 // on a cache line of its own, the photon-ID cursor of the pool kernel
@@ -2083,14 +2094,13 @@ int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint3
     if (!ctr || !key || !out) return fail(RT_ERR_ARG, "rt_selftest_philox: null argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(device_id));
-    uint32_t *d_in = nullptr, *d_out = nullptr;
-    RT_HIP(hipMalloc(&d_in, 16 * n));
-    RT_HIP(hipMalloc(&d_out, 16 * n));
-    RT_HIP(hipMemcpy(d_in, ctr, 16 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rt_selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, n, key[0], key[1], d_out);
+    HookBuffer<uint32_t> d_in, d_out;
+    RT_HIP(hipMalloc(&d_in.p, 16 * n));
+    RT_HIP(hipMalloc(&d_out.p, 16 * n));
+    RT_HIP(hipMemcpy(d_in.p, ctr, 16 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rt_selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in.p, n, key[0], key[1], d_out.p);
     RT_HIP(hipGetLastError());
-    RT_HIP(hipMemcpy(out, d_out, 16 * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_out);
+    RT_HIP(hipMemcpy(out, d_out.p, 16 * n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -2099,17 +2109,16 @@ int rt_selftest_exact(int device_id, int which, uint32_t first_bits, uint64_t co
     if (!out || which < 0 || which > 1) return fail(RT_ERR_ARG, "rt_selftest_exact: bad argument");
     if (count > (1ull << 32) - first_bits) return fail(RT_ERR_ARG, "rt_selftest_exact: range beyond 2^32 bit patterns");
     RT_HIP(hipSetDevice(device_id));
-    unsigned long long* d_out = nullptr;
+    HookBuffer<unsigned long long> d_out;
     const unsigned long long init[2] = {0ull, ~0ull};
-    RT_HIP(hipMalloc(&d_out, sizeof(init)));
-    RT_HIP(hipMemcpy(d_out, init, sizeof(init), hipMemcpyHostToDevice));
+    RT_HIP(hipMalloc(&d_out.p, sizeof(init)));
+    RT_HIP(hipMemcpy(d_out.p, init, sizeof(init), hipMemcpyHostToDevice));
     if (count > 0)
         hipLaunchKernelGGL(rt_selftest_exact_kernel, dim3(256 * 16), dim3(256), 0, 0, which, first_bits,
-                           (unsigned long long)count, d_out);
+                           (unsigned long long)count, d_out.p);
     RT_HIP(hipGetLastError());
     unsigned long long res[2];
-    RT_HIP(hipMemcpy(res, d_out, sizeof(res), hipMemcpyDeviceToHost));
-    (void)hipFree(d_out);
+    RT_HIP(hipMemcpy(res, d_out.p, sizeof(res), hipMemcpyDeviceToHost));
     out[0] = res[0]; out[1] = res[1];
     return RT_OK;
 }
@@ -2119,14 +2128,13 @@ int rt_selftest_math(int device_id, int which, const float* in, size_t n, float*
     if (!in || !out) return fail(RT_ERR_ARG, "rt_selftest_math: null argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(device_id));
-    float *d_in = nullptr, *d_out = nullptr;
-    RT_HIP(hipMalloc(&d_in, 4 * n));
-    RT_HIP(hipMalloc(&d_out, 4 * n));
-    RT_HIP(hipMemcpy(d_in, in, 4 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rt_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, d_in, n, d_out);
+    HookBuffer<float> d_in, d_out;
+    RT_HIP(hipMalloc(&d_in.p, 4 * n));
+    RT_HIP(hipMalloc(&d_out.p, 4 * n));
+    RT_HIP(hipMemcpy(d_in.p, in, 4 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rt_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, d_in.p, n, d_out.p);
     RT_HIP(hipGetLastError());
-    RT_HIP(hipMemcpy(out, d_out, 4 * n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_out);
+    RT_HIP(hipMemcpy(out, d_out.p, 4 * n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
