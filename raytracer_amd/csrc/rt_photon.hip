@@ -5,9 +5,10 @@
 //
 // Design:
 //  * photon state never touches HBM (the reference keeps it in global memory,
-//    raytracer_kernels.cu:360-473): the default kernel holds 128 photons per wave in LDS and
-//    compacts those waiting for the same stage (traverse / event / new direction) into full
-//    waves; lanes pull the next photon ID the moment a photon ends (regeneration, :477-498);
+//    raytracer_kernels.cu:360-473): the default kernel holds 128 photons per wave (48-byte records
+//    in LDS, ID words and step count in registers) and compacts those waiting for the same stage
+//    (traverse / event / new direction / outside-the-grid) into full waves; a slot whose photon ended
+//    takes the next photon ID of the wave's chunk (regeneration, :477-498);
 //  * Philox4x32-10 keyed on (seed, photon id, event index): tallies are integers, so the sum
 //    is independent of the launch shape, of the split over calls and of the GPU count;
 //  * optical properties as one 16-byte record per cell {k_tot, ssa, asy, k_cloud}: a collision
@@ -551,8 +552,9 @@ rt_trace_kernel(const TraceArgs a)
 // ------------------------------------------------------------------------------------------
 // Pool variant of the tracer: every wave keeps NS (> 64) photons in LDS and, each round, gathers
 // up to 64 of them that wait for the SAME stage into its lanes (ballot + rank compaction). The
-// three stages and all per-photon arithmetic are those of rt_trace_kernel above; only where the
-// photon state lives between rounds differs, so results are bit-identical. With 2-3 photons per
+// per-photon arithmetic is that of rt_trace_kernel above (its traverse stage split in two here: inside
+// the supervoxel grid, and the slab stage for everything outside it); only where the photon state
+// lives between rounds and the order of service differ, so results are bit-identical. With 2 photons per
 // lane in the pool, a round almost always finds a full wave of work for one stage (the lane-
 // resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
 // One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
