@@ -559,19 +559,22 @@ rt_trace_kernel(const TraceArgs a)
 // resident kernel splits its 64 photons over three stages and runs each at ~1/3 to 1/2 occupancy).
 // One wave per workgroup (no barriers anywhere), so LDS alone sets the residency.
 //
-// LDS per wave: NS records of three 16-byte groups (stored group-major), NS state bytes and a
-// 64-entry selection list (bytes):
+// LDS per wave: NS records of three 16-byte groups (stored group-major) and a 64-entry selection list
+// (bytes):
 //   g0 {x, y, z, tau}          tau holds 1/M of the region while the photon waits for its collision event
 //                              (the event stage draws the next tau before anything reads it)
 //   g1 {ux, uy, uz, ci | cj << 16}
-//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25}
+//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25 | alt << 26}
+//                              alt tells the two states of a stage apart (surface event, not collision;
+//                              reflection, not scattering): set by the slab stage on arrival at the surface
 //                              While a photon waits for stage S the first three hold {asy, u_mu, u_phi}: the
 //                              reciprocals are dead then. slab is a signed byte: -1 (below the surface) and
 //                              nslab (above the domain top) while a photon that has just left the atmosphere
 //                              waits for the slab stage
-// and, in three registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
-// that serves it, taken back by the owner at the end of the round), {pid_lo, pid_hi | nev << 8, nstep}.
-// 6336 bytes per wave at NS = 128: 25 waves share a CU's 160 KB (19 with the full 64-byte record in LDS).
+// and, in four registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
+// that serves it, taken back by the owner at the end of the round), {pid_lo, pid_hi | nev << 8, nstep, state}:
+// the selection of a round reads the states from registers, no memory. 6208 bytes per wave at NS = 128: 26 waves
+// share a CU's 160 KB (19 with the full 64-byte record in LDS).
 enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
 constexpr int kPoolRec = 12;
 #ifndef RT_FUSE_LAUNCH
@@ -748,12 +751,11 @@ rt_trace_pool_kernel(const TraceArgs a)
     using namespace rt;
     static_assert(NS % 16 == 0 && NS >= 64 && NS <= 256, "pool size");
     constexpr int kHalves = (NS + 63) / 64;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + kHalves * 16 + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + 16];
 
     const int lane = threadIdx.x;
     uint32_t* const rec = lds;                                              // NS records
-    uint8_t* const st = reinterpret_cast<uint8_t*>(rec + NS * kPoolRec);    // state bytes (padded to kHalves*64)
-    uint8_t* const sel = st + kHalves * 64;                                 // 64 selected slots
+    uint8_t* const sel = reinterpret_cast<uint8_t*>(rec + NS * kPoolRec);   // 64 selected slots
 
     // photon IDs of this wave: wave_left IDs from wave_next on, a chunk taken from the device-wide cursor
     uint64_t wave_next = 0;
@@ -763,9 +765,11 @@ rt_trace_pool_kernel(const TraceArgs a)
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
 
+    // state (PS_*) of the slots this lane owns: selection needs no memory at all
+    uint32_t stv[kHalves];
 #pragma unroll
     for (int h = 0; h < kHalves; ++h)
-        st[h * 64 + lane] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
+        stv[h] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
     int n_t = 0, n_e = 0, n_s = 0, n_x = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
     // photon ID words of the slots this lane owns (slot h * 64 + lane): {pid_lo, pid_hi | nev << 8}. Only the
     // event and launch stages touch them; keeping them out of LDS is what lets 22 waves share a CU
@@ -795,7 +799,7 @@ rt_trace_pool_kernel(const TraceArgs a)
         for (int h = 0; h < kHalves; ++h)
         {
             const uint32_t sidx = h * 64 + lane;
-            const bool match = (st[sidx] >> 2) == cls;
+            const bool match = (stv[h] >> 2) == cls;
             const unsigned long long m = __ballot(match);
             const int rank = found + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (match && rank < 64)
@@ -832,10 +836,10 @@ rt_trace_pool_kernel(const TraceArgs a)
             if (STATS) { ++rounds_s; lanes_s += n; }
             if (active)
             {
-                const uint32_t state = st[slot];
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, cks}
                 const uint32_t cks = __float_as_uint(g2.w);
+                const uint32_t state = (cks >> 26) & 1u ? PS_REFLECT : PS_SCATTER;
                 // the majorant of the photon's region for the traverse step at the end of this stage: asked for
                 // now, so that the scattering arithmetic runs while the gather is under way
                 const uint32_t cicj = __float_as_uint(g1.w);
@@ -939,13 +943,13 @@ rt_trace_pool_kernel(const TraceArgs a)
             }
             if (active)
             {
-                const uint32_t state = st[slot];
                 uint32_t cell = 0;
                 float inv_m = 0.0f;
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
                 const uint32_t pid_hi = pn & 0xffu;
                 uint32_t nev = pn >> 8;
                 const uint32_t cks = RW(11);
+                const uint32_t state = (cks >> 26) & 1u ? PS_SURFACE : PS_COLLIDE;
                 {
                     // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
                     // dead until the draw below); a photon on the surface has its column from (x, y)
@@ -1097,7 +1101,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
                 R4(0) = make_float4(x, y, z, tau);
                 R4(1) = make_float4(sun_x, sun_y, sun_z, __uint_as_float(cicj));
-                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz, __uint_as_float(ck | (((uint32_t)slab & 0xffu) << 16)));
+                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz,
+                                    __uint_as_float(ck | (((uint32_t)slab & 0xffu) << 16) | (ns == PS_SURFACE ? 1u << 26 : 0u)));
                 out_lo = pid_lo;
                 out_hn = pid_hi | (1u << 8);
             }
@@ -1138,7 +1143,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 R4(0) = make_float4(x, y, z, tau);
                 if (ns == PS_TRAVERSE)
                     RW(7) = cicj;
-                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
+                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u);
             }
         }
         else
@@ -1165,6 +1170,12 @@ rt_trace_pool_kernel(const TraceArgs a)
 #undef R4
 #undef RW
         // ---- the owners of the served slots take the new ID words from the lanes that served them ----
+#pragma unroll
+        for (int h = 0; h < kHalves; ++h)
+        {
+            const uint32_t v = BPERM((uint32_t)srv[h] & 63u, ns);
+            if (srv[h] >= 0) stv[h] = v;
+        }
         if (cls != 1u)
         {
 #pragma unroll
@@ -1193,9 +1204,7 @@ rt_trace_pool_kernel(const TraceArgs a)
             }
         }
 #undef BPERM
-        // ---- publish the new states and update the stage counts ----
-        if (active)
-            st[slot] = (uint8_t)ns;
+        // ---- update the stage counts ----
         const uint32_t ncls = active ? (ns >> 2) : 5u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
                   d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
@@ -1864,7 +1873,7 @@ int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         const int ns = c->pool;
         if (a.pid_end > (1ull << 40))
             return fail(RT_ERR_ARG, "rt_trace: the pool kernel packs photon ids into 40 bits");
-        const size_t lds_bytes = ((size_t)ns * kPoolRec + (size_t)((ns + 63) / 64) * 16 + 16) * 4;
+        const size_t lds_bytes = ((size_t)ns * kPoolRec + 16) * 4;
         int per_cu = (int)((160u * 1024u) / lds_bytes);
         if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
         if (per_cu < 1) per_cu = 1;
