@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on one GPU: random small scenes (ragged grids, clouds that touch the surface or the
+domain top, cloud-free and gas-free columns, a single slab) x random options (pool size, supervoxel size, region
+levels, launch order, planar scattering, fixed dot, chunk, launch threshold) x random photon ID ranges, the HIP
+kernels against oracle/photon_oracle.c, every tally and event counter bit for bit.
+
+Test infrastructure like tests/ (it calls the oracle as the checker). Usage, on the GPU box:
+    python tools/fuzz_parity.py [cases=200] [first_case=0]
+Exit status 1 and the failing case's parameters on the first difference."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O          # noqa: E402
+import raytracer_amd as rt      # noqa: E402
+
+
+def random_scene(rng):
+    S = rt.scenes
+    f = np.float32
+    itot, jtot, ktot = int(rng.integers(3, 41)), int(rng.integers(3, 41)), int(rng.integers(2, 25))
+    dx, dy, dz = float(rng.uniform(20, 200)), float(rng.uniform(20, 200)), float(rng.uniform(10, 120))
+    ztop = ktot * dz
+    kind = rng.choice(["clouds", "deck", "clear", "to_ground", "to_top", "everywhere"])
+    k_gas = float(rng.choice([0.0, 1e-5, 1e-4, 1e-3]))
+    ssa_gas = float(rng.choice([1.0, 0.5, 0.9]))
+    asy_cloud = float(rng.choice([0.85, 0.0, -0.4, 0.5, 0.95, 5e-4]))
+    ssa_cloud = float(rng.choice([1.0, 0.9, 0.6]))
+    kc_lo = float(rng.choice([1e-3, 5e-3, 2e-2]))
+    if kind == "clear":
+        sc = S.cumulus(itot, jtot, ktot, dx, dy, dz, n_clouds=0, seed=int(rng.integers(1 << 30)), k_gas=max(k_gas, 1e-5),
+                       ssa_gas=ssa_gas, name="fuzz_clear")
+    else:
+        zb, zt = {"clouds": (0.25 * ztop, 0.7 * ztop), "deck": (0.3 * ztop, 0.5 * ztop), "to_ground": (0.0, 0.5 * ztop),
+                  "to_top": (0.5 * ztop, ztop), "everywhere": (0.0, ztop)}[kind]
+        sc = S.cumulus(itot, jtot, ktot, dx, dy, dz, n_clouds=int(rng.integers(1, 8)), seed=int(rng.integers(1 << 30)),
+                       z_base=zb, z_top=zt, k_gas=k_gas, ssa_gas=ssa_gas, ssa_cloud=ssa_cloud, asy_cloud=asy_cloud,
+                       k_cloud_range=(kc_lo, kc_lo * 8), name="fuzz_" + kind)
+        if kind in ("deck", "everywhere"):
+            # a closed layer: every column of some levels is cloudy
+            k0, k1 = int(zb / dz), max(int(zb / dz) + 1, int(zt / dz))
+            kc = sc.k_cloud.copy()
+            kc[k0:k1] = np.maximum(kc[k0:k1], f(kc_lo))
+            ssa, asy = S._mix(sc.k_gas, ssa_gas, 0.0, kc, ssa_cloud, asy_cloud)
+            sc = S.Scene(sc.name, itot, jtot, ktot, dx, dy, dz, sc.k_gas, kc, ssa, asy)
+    sc.albedo = float(rng.choice([0.0, 0.2, 0.7, 1.0]))
+    sc.zenith_deg = float(rng.choice([0.0, 20.0, 50.0, 75.0, 88.0]))
+    sc.azimuth_deg = float(rng.choice([0.0, 20.0, 90.0, 213.0]))
+    return sc, kind
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for case in range(first, first + cases):
+        rng = np.random.default_rng(1000 + case)
+        scene, kind = random_scene(rng)
+        pool = int(rng.choice([0, 64, 96, 128, 128, 160, 192, 256]))
+        sg = (0, 0, 0) if rng.random() < 0.15 else tuple(int(v) for v in rng.integers(1, 9, size=3))
+        levels = int(rng.integers(0, 6))
+        tau_milli = int(rng.choice([0, 37, 500, 2000, 100000]))
+        log2k = int(rng.choice([-1, -1, 0, 2, 5]))
+        planar = bool(pool != 0 and rng.random() < 0.2)
+        fixed_dot = bool(rng.random() < 0.3)
+        chunk = int(rng.choice([64, 256, 1024]))
+        thl = int(rng.choice([1, 16, 40, 100]))
+        n = int(rng.choice([1, 63, 1000, 20000, 60000]))
+        pid0 = int(rng.integers(0, 1 << 39))
+        seed = int(rng.integers(0, 1 << 62))
+        desc = dict(case=case, kind=kind, grid=(scene.itot, scene.jtot, scene.ktot), albedo=scene.albedo, zenith=scene.zenith_deg,
+                    pool=pool, supergrid=sg, levels=levels, tau_milli=tau_milli, log2k=log2k, planar=planar,
+                    fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0)
+        tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels, merge_tau_milli=tau_milli,
+                                        launch_log2k=log2k, planar=int(planar), fixed_dot=int(fixed_dot), chunk=chunk,
+                                        th_launch=thl)
+        tr.set_supergrid(*sg)
+        tr.trace(seed, pid0, n)
+        tr.synchronize()
+        got, gev = tr.tallies(), tr.events()
+        tr.close()
+        want, wev = O.photon_oracle(scene, seed, pid0, n, fixed_dot=fixed_dot, supergrid=sg, launch_log2k=log2k,
+                                    planar=planar, levels=levels, merge_tau=np.float32(tau_milli / 1000.0))
+        bad = [name for name in O.TALLY_NAMES if not np.array_equal(got[name], want[name])]
+        if bad or gev != wev:
+            print("MISMATCH", desc, "tallies:", bad, "events gpu/oracle:", gev, wev, flush=True)
+            return 1
+        if case % 20 == 0:
+            print("ok", desc, flush=True)
+    print(f"{cases} cases bit-identical", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
