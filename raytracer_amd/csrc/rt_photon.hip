@@ -580,6 +580,12 @@ constexpr int kPoolRec = 12;
 #ifndef RT_FUSE_LAUNCH
 #define RT_FUSE_LAUNCH 1
 #endif
+// Wave priority from the start of a round until its gather has been issued (s_setprio; back to 0 for the
+// arithmetic that follows): a wave that is about to ask memory for something goes first, so more gathers are under
+// way at any time (+1 %)
+#ifndef RT_PRIO
+#define RT_PRIO 1
+#endif
 #ifndef RT_TH_SLAB
 #define RT_TH_SLAB 16       // photons waiting for the slab stage that get it served ahead of the larger stages
 #endif
@@ -607,6 +613,7 @@ constexpr int kPoolBlock = 64;
                     ++nstep; \
                     if (STATS) ++ev_step; \
                     const float2 mm = (MM); \
+                    __builtin_amdgcn_s_setprio(0); \
                     const int L = HIER ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
                     if (HIER) \
@@ -792,6 +799,7 @@ rt_trace_pool_kernel(const TraceArgs a)
             cls = 3u;
 
         // ---- gather up to 64 waiting slots into the lanes ----
+        __builtin_amdgcn_s_setprio(RT_PRIO);
         asm volatile("" ::: "memory");
         int found = 0;
         int srv[kHalves];                // the lane that serves slot h * 64 + lane this round, or -1
@@ -848,6 +856,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 float2 mm_pre = make_float2(0.0f, 0.0f);
                 if (slab == a.gslab)
                     mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
+                __builtin_amdgcn_s_setprio(0);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
                 float sp = 0.0f, cp = 0.0f;
                 if (!a.planar)
@@ -963,6 +972,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                         cr = a.cells[cell];
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 const float kt = cr.x;
                 // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
                 // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
@@ -1022,6 +1032,7 @@ rt_trace_pool_kernel(const TraceArgs a)
         else if (__builtin_expect(cls == 3u, 0))
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
+            __builtin_amdgcn_s_setprio(0);
             const LaunchBlock* const lb = a.launch;
             while (__builtin_expect(wave_left == 0u && ranges_dry < (uint32_t)kXcds, 0))
             {
@@ -1128,6 +1139,7 @@ rt_trace_pool_kernel(const TraceArgs a)
         else if (__builtin_expect(cls == 4u, 0))
         {
             // ---- slab stage: everything outside the grid ----
+            __builtin_amdgcn_s_setprio(0);
             if (STATS) { ++rounds_x; lanes_x += n; }
             if (active)
             {
