@@ -152,9 +152,17 @@ int rt_set_stream(rt_context* ctx, void* hip_stream);
  * events to the device tallies (the restart-friendly accumulation raytracer_3d.cu:89 intends).
  * Every random number is Philox4x32-10(key = seed, counter = (photon id, step, purpose)), so the
  * tallies of a photon range do not depend on how it is split over calls, launches or GPUs.
- * Asynchronous on the context's stream. Stands in for the ray_tracer_kernel launch,
- * raytracer_3d.cu:151-163 (kernel: raytracer_kernels.cu:307-569). */
+ * Asynchronous on the context's stream. The default (pool) kernel packs photon ids into 40 bits: ranges that end
+ * beyond 2^40 are refused (RT_ERR_ARG) unless option "pool" = 0 selects the lane-resident kernel, which carries
+ * 64-bit ids. Stands in for the ray_tracer_kernel launch, raytracer_3d.cu:151-163 (kernel:
+ * raytracer_kernels.cu:307-569). */
 int rt_trace(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t photon_count);
+
+/* Runs everything rt_trace would otherwise do on its first call after rt_upload_optics or an option change:
+ * the device pre-pass over supervoxels and the host-side merge into majorant regions (allocates the tables).
+ * Calling it ahead of a timed or latency-critical section makes every rt_trace in it a pure asynchronous
+ * launch. Part of what cloud_mask_kernel's launch stands for (raytracer_3d.cu:116-130). */
+int rt_prepare(rt_context* ctx);
 
 /* Blocks until the context's stream is idle (cudaDeviceSynchronize at raytracer_3d.cu:165) and
  * reports RT_ERR_ABORTED (once) if any photon hit the step guard since the last call. */
@@ -179,7 +187,9 @@ int rt_tally_device_buffer(rt_context* ctx, void** device_ptr, size_t* n_words);
 
 /* Makes the context accumulate into a caller-owned device buffer of the same layout (e.g. a
  * tensor the host framework allocated, so that it can hand it to its collective). The buffer must
- * outlive the context or a later rebind; its current contents are kept (not zeroed). */
+ * outlive the context or a later rebind; its current contents are kept (not zeroed). The switch is in stream
+ * order: launches already enqueued keep the buffer they were given, and the call does not wait for them (it
+ * waits only when the buffer it replaces is the context's own, which it frees). */
 int rt_bind_tally_buffer(rt_context* ctx, void* device_ptr, size_t n_words);
 
 /* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
@@ -213,8 +223,8 @@ int rt_last_trace_ms(rt_context* ctx, float* ms);
 /* Test hook: Philox4x32-10 on the device, n counter blocks (4 words each) under one key. */
 int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint32_t key[2], uint32_t* out);
 
-/* Test hook: evaluates the device math (0 = log, 1 = x^(-1/3), 2 = sin(2*pi*x), 3 = cos(2*pi*x)) on n
- * host floats. */
+/* Test hook: evaluates the device math (0 = log, 1 = x^(-1/3), 2 = sin(2*pi*x), 3 = cos(2*pi*x), 4 = the
+ * Rayleigh cosine of a uniform draw, 5 = the Henyey-Greenstein cosine at g = 0.85) on n host floats. */
 int rt_selftest_math(int device_id, int which, const float* in, size_t n, float* out);
 
 /* Test hook: the device's short sqrt (which = 0) or reciprocal (which = 1) against the compiler's IEEE

@@ -170,9 +170,10 @@ static inline float henyey_mu(float g, float r)
     const float one_m_g2 = 1.0f - g * g;
     const float a = one_m_g2 * one_m_g2;
     const float h = fmaf(2.0f * r, g, 1.0f - g);
-    const float b = (2.0f * g) * (h * h);
-    const float c = -g * 0.5f - 1.0f / (2.0f * g);
-    return -(a / b) - c;
+    const float h2 = h * h;
+    const float rb = 1.0f / ((2.0f * g) * h2);       /* 1/b; then 1/(2g) = h^2 / b: one reciprocal, no division */
+    const float c = -g * 0.5f - h2 * rb;
+    return -(a * rb) - c;
 }
 
 /* exported for the sampler-moment tests */
@@ -245,6 +246,16 @@ typedef struct
 
 void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->lvl); s->lvl = NULL; }
 
+/* 1/M as the tables hold it: finite. A region without any extinction has M = 0 (or, once the region level
+ * is packed into M's low mantissa bits, a denormal) and 1/M = +inf; the traverse step computes tau * (1/M), which
+ * is NaN for tau == 0 (one launch in 2^24 draws exactly 0). With FLT_MAX instead, tau == 0 stops the photon where
+ * it is for a collision test that is null (k_tot = 0 there, and 0 * FLT_MAX = 0) and draws the next tau; any
+ * tau > 0 still carries the photon through the whole region. */
+static inline float majorant_reciprocal(float m)
+{
+    return fminf(1.0f / m, FLT_MAX);
+}
+
 /* Region hierarchy over the supervoxel grid, built bottom-up: the aligned cube of 2^L supervoxels per edge
  * (clipped at the grid) becomes one region if all its members are regions of level L-1 and
  * (M - mean k_tot) * (2^L * edge) <= tau, with M the maximum and mean the volume mean of the extinction
@@ -288,7 +299,7 @@ static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, 
                                 const size_t e = ((size_t)k * ncj + j) * nci + i;
                                 lvl[e] = (unsigned char)L;
                                 maj[2 * e] = m;
-                                maj[2 * e + 1] = 1.0f / m;
+                                maj[2 * e + 1] = majorant_reciprocal(m);
                             }
                 }
     }
@@ -301,7 +312,7 @@ static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, 
         memcpy(&bits, &maj[2 * e], 4);
         bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
         memcpy(&maj[2 * e], &bits, 4);
-        maj[2 * e + 1] = 1.0f / maj[2 * e];
+        maj[2 * e + 1] = majorant_reciprocal(maj[2 * e]);
     }
 }
 
@@ -344,7 +355,7 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         float m = 0.0f;
         for (int k = lo[s]; k < hi[s]; ++k) if (lev_max[k] > m) m = lev_max[k];
         out->kmaj[s] = m;
-        out->inv_kmaj[s] = 1.0f / m;
+        out->inv_kmaj[s] = majorant_reciprocal(m);
         out->zface[s] = (float)lo[s] * sc->dz;
     }
     out->zface[n] = (float)sc->ktot * sc->dz;
@@ -392,7 +403,7 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
                             }
                     const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
                     out->maj[2 * e] = m;
-                    out->maj[2 * e + 1] = 1.0f / m;
+                    out->maj[2 * e + 1] = majorant_reciprocal(m);
                     ksum[e] = sum;
                     kcnt[e] = cnt;
                 }
@@ -543,7 +554,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         float t_exit = tx; int axis = gridded ? 0 : 2;           /* a clear-air slab has only its z faces */
         if (ty < t_exit) { t_exit = ty; axis = 1; }
         if (tz < t_exit) { t_exit = tz; axis = 2; }
-        const float dn = M > 0.0f ? tau * invM : INFINITY;       /* raytracer_kernels.cu:367 */
+        const float dn = tau * invM;                             /* raytracer_kernels.cu:367; invM is finite */
         const int hit = t_exit <= dn;
         const float tt = hit ? t_exit : dn;
         x = fmaf(ux, tt, x); y = fmaf(uy, tt, y); z = fmaf(uz, tt, z);

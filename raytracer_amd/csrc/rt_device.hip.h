@@ -166,9 +166,11 @@ __device__ __forceinline__ float henyey_mu(float g, float r)
     const float one_m_g2 = 1.0f - g * g;
     const float a = one_m_g2 * one_m_g2;
     const float h = fma_(2.0f * r, g, 1.0f - g);
-    const float b = (2.0f * g) * (h * h);
-    const float c = -g * 0.5f - rt_rcp(2.0f * g);          // 2e-3 <= |2 g| < 2
-    return -(a / b) - c;
+    const float h2 = h * h;
+    // one reciprocal serves both quotients: 1/b, and 1/(2g) = h^2 / b; 7e-18 < |b| < 8
+    const float rb = rt_rcp((2.0f * g) * h2);
+    const float c = -g * 0.5f - h2 * rb;
+    return -(a * rb) - c;
 }
 
 __device__ __forceinline__ float free_path_tau(float r) { return -rt_log((1.0f - r) + RT_EPS); }

@@ -70,9 +70,8 @@ constexpr int kCursorWord = 32;
 constexpr int kCursorStride = 16;     // words between the cursors of two XCDs: a 128-byte line each
 constexpr int kXcds = 8;
 constexpr int kEventWords = kCursorWord + kXcds * kCursorStride;
-
 // ------------------------------------------------------------------------------------------
-// Kernel arguments of the tracer (by value: they live in SGPRs).
+// Kernel arguments of the lane-resident tracer (by value: they live in SGPRs).
 struct TraceArgs
 {
     const float4* cells;      // {k_tot = gas + cloud, ssa, asy, k_cloud} per cell [k][j][i]: one 16-byte
@@ -80,7 +79,7 @@ struct TraceArgs
     const float2* maj;        // {M, 1/M} of the region a supervoxel belongs to: ncoarse supervoxels
                               // [ck][cj][ci], then one entry per slab. The three low mantissa bits of a
                               // supervoxel's M hold its region level: the region is the aligned cube of 2^level
-                              // supervoxels per edge around it
+                              // supervoxels per edge around it. 1/M is finite (FLT_MAX where M is 0)
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
     uint64_t seed;
@@ -99,39 +98,63 @@ struct TraceArgs
     uint32_t ncoarse;
     float hx, hy, hz, inv_hx, inv_hy, inv_hz, zc0, zc1;
     int th_event, th_scatter, low_traverse;   // wave scheduling thresholds (lanes)
-    int th_launch;            // pool kernel: waiting launches that trigger a launch round
     // stratified launch (launch_log2k >= 0): 2^k consecutive photon IDs per column, columns in
     // row-major order, each pass over the columns rotated by a per-pass random offset
     int launch_log2k;
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
-    int planar;               // pool kernel: scattering rule of the reference's 2D tracer (directions stay in x-z)
-    const struct LaunchBlock* launch;         // pool kernel: see LaunchBlock
-    // pool kernel: photon IDs are handed out in chunks from device-wide cursors, so the launch needs
-    // no static partition (waves that start late or run slower simply take fewer chunks). One cursor
-    // per XCD (kCursorStride words apart), each over its own eighth of the ID range: with the
-    // stratified launch an XCD then sweeps its own band of columns and its private L2 keeps that band's
-    // cells; a wave whose XCD has run dry takes chunks from the next XCD's range.
-    unsigned long long* cursor;               // (the pool kernel reaches the event counters as cursor - kCursorWord:
-                                              // one live pointer less in a loop that is short of SGPRs)
 };
 
-// What only the launch (regeneration) stage and the surface event of the pool kernel need. It lives
-// in device memory, not in the kernel arguments, so that these values are fetched where they are
-// used instead of occupying scalar registers through every round of the wave's loop (the loop
-// is short of SGPRs; every spilled one costs a v_readlane per use). Read-only while the tracer runs
-// (the cursor sits elsewhere: a line that takes atomics must not also serve these loads). Written by
-// rt_launch_block_kernel on the stream before each pool launch.
-struct LaunchBlock
+// Kernel arguments of the pool tracer: only what its three frequent stages (traverse, event, new direction) use
+// in every round. The wave's loop is short of scalar registers (every spilled one costs a v_readlane per use), so
+// everything the rare stages need -- launch, slab stage, surface event, the abort path, statistics -- lives in
+// the ColdBlock in device memory and is fetched with scalar loads where it is used.
+struct PoolArgs
+{
+    const float4* cells;          // as TraceArgs
+    const float2* maj;
+    unsigned long long* tallies;
+    const struct ColdBlock* cold;
+    // Photon IDs are handed out in chunks from device-wide cursors, so the launch needs no static partition
+    // (waves that start late or run slower simply take fewer chunks). One cursor per XCD (kCursorStride words
+    // apart), each over its own eighth of the ID range: with the stratified launch an XCD then sweeps its own
+    // band of columns and its private L2 keeps that band's cells; a wave whose XCD has run dry takes chunks from
+    // the next XCD's range.
+    unsigned long long* cursor;
+    uint64_t seed;
+    int itot, jtot, ktot;
+    uint32_t ncol;
+    int gslab, nci, ncj, nck;
+    int th_launch;                // waiting launches that trigger a launch round
+    float xs, ys, inv_dx, inv_dy, inv_dz;
+    float hx, hy, hz, inv_hx, inv_hy, inv_hz, zc0, zc1;
+};
+
+// Read-only while the tracer runs (the cursors sit elsewhere: a line that takes atomics must not also serve
+// these loads). Written by rt_launch_block_kernel on the stream before each pool launch.
+struct ColdBlock
 {
     uint64_t pid_begin, total;
-    uint64_t sub_size;        // IDs per XCD range (a multiple of chunk)
+    uint64_t sub_size;            // IDs per XCD range (a multiple of chunk)
+    unsigned long long* events;   // RT_N_EVENTS counters, then the scheduler statistics
     uint32_t chunk;
     int launch_log2k;
     float sun_x, sun_y, sun_z, inv_sun_x, inv_sun_y, inv_sun_z;
     float ztop, dx, dy, albedo;
     uint32_t div_itot_mul, div_itot_shift;
+    float zface[4];
+    float inv_xs, inv_ys;
+    uint32_t ncoarse;
+    int nslab;
 };
+
+// The cold block through the constant address space: its contents do not change while the tracer runs (the kernel
+// before it on the stream wrote them), so wave-uniform reads of it are scalar loads, not vector memory traffic.
+typedef const __attribute__((address_space(4))) ColdBlock* ColdPtr;
+__device__ __forceinline__ ColdPtr cold_of(const PoolArgs& a)
+{
+    return (ColdPtr)(uintptr_t)a.cold;
+}
 
 __device__ __forceinline__ void tally_add(unsigned long long* p, unsigned long long v = 1ull)
 {
@@ -447,7 +470,7 @@ rt_trace_kernel(const TraceArgs a)
                     float t_exit = tx; int axis = gridded ? 0 : 2;      // a clear-air slab has only its z faces
                     if (ty < t_exit) { t_exit = ty; axis = 1; }
                     if (tz < t_exit) { t_exit = tz; axis = 2; }
-                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff();   // raytracer_kernels.cu:367
+                    const float dn = tau * mm.y;          // raytracer_kernels.cu:367; 1/M is finite in the tables
                     const bool hit = t_exit <= dn;
                     const float tt = hit ? t_exit : dn;
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
@@ -564,19 +587,34 @@ rt_trace_kernel(const TraceArgs a)
 //   g0 {x, y, z, tau}          tau holds 1/M of the region while the photon waits for its collision event
 //                              (the event stage draws the next tau before anything reads it)
 //   g1 {ux, uy, uz, ci | cj << 16}
-//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25 | alt << 26}
+//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25 | alt << 26 | age << 27}
 //                              alt tells the two states of a stage apart (surface event, not collision;
 //                              reflection, not scattering): set by the slab stage on arrival at the surface
 //                              While a photon waits for stage S the first three hold {asy, u_mu, u_phi}: the
 //                              reciprocals are dead then. slab is a signed byte: -1 (below the surface) and
 //                              nslab (above the domain top) while a photon that has just left the atmosphere
-//                              waits for the slab stage
-// and, in four registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
-// that serves it, taken back by the owner at the end of the round), {pid_lo, pid_hi | nev << 8, nstep, state}:
+//                              waits for the slab stage. age is the step guard (below)
+// and, in three registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
+// that serves it, taken back by the owner at the end of the round), {pid_lo, pid_hi | nev << 8, state}:
 // the selection of a round reads the states from registers, no memory. 6208 bytes per wave at NS = 128: 26 waves
 // share a CU's 160 KB (19 with the full 64-byte record in LDS).
+//
+// Step guard. Every wave must drain, so a photon that never ends (a non-finite state, or a bug that makes it
+// cross faces forever) has to be retired: the lane-resident kernel and the oracle count its steps up to
+// RT_MAX_STEPS = 2^22. Here a count per photon would be one more word to carry between the owner and the serving
+// lane every round, so the guard is kept in time instead: every kTickRounds-th round of the wave is a tick (wave-
+// uniform), a photon served by a stepping stage in a tick round ages by one (5 bits of the record), and one that
+// is still there at age 31 is abandoned (RT_EV_ABORT; rt_synchronize reports it) -- after about 31 * 2^17 = 2^22
+// rounds of its wave, the same order as the step limit. A photon is served at most once per round, so no photon
+// is retired before it has had the chance of that many steps only if it is served every round; a photon of a
+// valid run ends after tens of steps and at most a handful of ticks can pass in a wave's whole life (a launch of
+// 2^28 photons is about 2 * 10^4 rounds per wave), so the guard cannot fire on one. Non-finite positions are
+// caught in the step itself, at once.
 enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
+enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
+constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
+constexpr uint32_t kTickRounds = 1u << 17;
 #ifndef RT_FUSE_LAUNCH
 #define RT_FUSE_LAUNCH 1
 #endif
@@ -589,10 +627,15 @@ constexpr int kPoolRec = 12;
 #ifndef RT_TH_SLAB
 #define RT_TH_SLAB 16       // photons waiting for the slab stage that get it served ahead of the larger stages
 #endif
+// traverse steps a lane may take in one round of the traverse stage (a lane that crossed a face inside the grid
+// goes on into the next region at once instead of waiting for the next round)
+#ifndef RT_T_STEPS
+#define RT_T_STEPS 1
+#endif
 constexpr int kPoolBlock = 64;
 
 // One traverse step of the pool kernel INSIDE THE GRIDDED SLAB on the photon held in the lane's locals (x, y,
-// z, tau, ux, uy, uz, nstep, ci, cj, ck, slab, ns): cross one majorant region or stop at the collision site
+// z, tau, ux, uy, uz, age, ci, cj, ck, slab, ns): cross one majorant region or stop at the collision site
 // (tau then carries 1/M of the region to the event stage, which draws the next tau anyway);
 // IX, IY, IZ are the direction reciprocals. Used by the traverse stage and, fused, at the end of the new-
 // direction stage (a photon that has just been given a direction always traverses next: doing it in the same
@@ -601,16 +644,17 @@ constexpr int kPoolBlock = 64;
 // arithmetic. Inside a merged region the supervoxel indices follow the position (kept within the region: a
 // coordinate on one of its faces may round to the neighbour's side). A photon that leaves the slab through
 // its top or bottom moves its slab index and waits for the slab stage (PS_SLAB), which owns everything
-// outside the grid: the clear-air slabs, the domain top and the surface.
+// outside the grid: the clear-air slabs, the domain top and the surface. 1/M is finite in the tables
+// (majorant_reciprocal), so tau * (1/M) is a number whatever the region holds.
 #define RT_TRAVERSE_STEP(IX, IY, IZ, MM) \
-                if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
+                if (__builtin_expect(!(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask), 0)) \
                 { \
-                    tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]); \
+                    tally_add(&cold_of(a)->events[RT_EV_ABORT]); \
                     ns = PS_LAUNCH; \
                 } \
                 else \
                 { \
-                    ++nstep; \
+                    age += age_inc; \
                     if (STATS) ++ev_step; \
                     const float2 mm = (MM); \
                     __builtin_amdgcn_s_setprio(0); \
@@ -633,7 +677,7 @@ constexpr int kPoolBlock = 64;
                     float t_exit = tx; int axis = 0; \
                     if (ty < t_exit) { t_exit = ty; axis = 1; } \
                     if (tz < t_exit) { t_exit = tz; axis = 2; } \
-                    const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff(); \
+                    const float dn = tau * mm.y; \
                     const bool hit = t_exit <= dn; \
                     const float tt = hit ? t_exit : dn; \
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z); \
@@ -675,38 +719,40 @@ constexpr int kPoolBlock = 64;
                     } \
                 }
 
-// One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, nstep, slab, cicj,
-// ck, ns; UX, UY, UZ the direction, IZ the reciprocal of its z component, up = IZ > 0): everything outside the
-// grid. A photon inside a clear-air slab takes its step there (to the slab's top or bottom face, or to a
-// collision site under the slab's own majorant, raytracer_kernels.cu:366-415 with the slab as the only
-// region); a photon that reaches a face -- this way or by leaving the grid in the traverse stage -- arrives at
-// the domain top (raytracer_kernels.cu:487-499), at the surface (:455-460; the albedo draw is stage E) or in
+// One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, age, slab, cicj,
+// ck, ns; UX, UY, UZ the direction, IZ the reciprocal of its z component, up = IZ > 0; cb the cold block):
+// everything outside the grid. A photon inside a clear-air slab takes its step there (to the slab's top or bottom
+// face, or to a collision site under the slab's own majorant, raytracer_kernels.cu:366-415 with the slab as the
+// only region); a photon that reaches a face -- this way or by leaving the grid in the traverse stage -- arrives
+// at the domain top (raytracer_kernels.cu:487-499), at the surface (:455-460; the albedo draw is stage E) or in
 // the next slab. Used by the slab stage and, fused, at the end of the launch stage (every photon starts with
-// this step when clear air lies above the clouds).
+// this step when clear air lies above the clouds). The surface and top-of-domain tallies of a round are
+// aggregated over runs of neighbouring lanes that hit the same column (RT_SLAB_TALLY below).
 #define RT_SLAB_STEP(UX, UY, UZ, IZ, DIFFUSE) \
                 bool on_face = true; \
                 ns = PS_SLAB; \
-                if (slab >= 0 && slab < a.nslab) \
+                const int nslab_ = cb->nslab; \
+                if (slab >= 0 && slab < nslab_) \
                 { \
-                    if (__builtin_expect(nstep >= RT_MAX_STEPS || !(z == z) || !(x == x) || !(y == y), 0)) \
+                    if (__builtin_expect(!(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask), 0)) \
                     { \
-                        tally_add(&(a.cursor - kCursorWord)[RT_EV_ABORT]); \
+                        tally_add(&cb->events[RT_EV_ABORT]); \
                         ns = PS_LAUNCH; \
                         on_face = false; \
                     } \
                     else \
                     { \
-                        ++nstep; \
+                        age += age_inc; \
                         if (STATS) ++ev_step; \
-                        const float2 mm = a.maj[a.ncoarse + (uint32_t)slab]; \
+                        const float2 mm = a.maj[cb->ncoarse + (uint32_t)slab]; \
                         const int fi = up ? slab + 1 : slab; \
-                        const float fz = fi == 0 ? a.zface[0] : (fi == 1 ? a.zface[1] : (fi == 2 ? a.zface[2] : a.zface[3])); \
+                        const float fz = fi == 0 ? cb->zface[0] : (fi == 1 ? cb->zface[1] : (fi == 2 ? cb->zface[2] : cb->zface[3])); \
                         const float tz = face_distance(fz, z, (IZ)); \
-                        const float dn = mm.x > 0.0f ? tau * mm.y : __builtin_inff(); \
+                        const float dn = tau * mm.y; \
                         const bool hit = tz <= dn; \
                         const float tt = hit ? tz : dn; \
                         x = fma_((UX), tt, x); y = fma_((UY), tt, y); z = fma_((UZ), tt, z); \
-                        x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); \
+                        x = wrap_periodic(x, a.xs, cb->inv_xs); y = wrap_periodic(y, a.ys, cb->inv_ys); \
                         if (!hit) \
                         { \
                             ns = PS_COLLIDE; \
@@ -725,21 +771,21 @@ constexpr int kPoolBlock = 64;
                 } \
                 if (on_face) \
                 { \
-                    if (slab < 0 || slab >= a.nslab) \
+                    if (slab < 0 || slab >= nslab_) \
                     { \
                         const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot); \
                         const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot; \
                         if (slab < 0) \
                         { \
                             if (STATS) ++ev_sfc; \
-                            tally_add(&a.tallies[((DIFFUSE) ? 3u : 2u) * a.ncol + ij]); \
+                            tally_word = ((DIFFUSE) ? 3u : 2u) * a.ncol + ij; \
                             slab = 0; \
                             ns = PS_SURFACE; \
                         } \
                         else \
                         { \
                             if (STATS) ++ev_toa; \
-                            tally_add(&a.tallies[a.ncol + ij]); \
+                            tally_word = a.ncol + ij; \
                             ns = PS_LAUNCH; \
                         } \
                     } \
@@ -751,13 +797,34 @@ constexpr int kPoolBlock = 64;
                     } \
                 }
 
-template <bool FIXED_DOT, bool STATS, int NS, bool HIER>
+// Per-wave aggregation of a round's 2-D tallies (north_star; the reference adds one by one,
+// raytracer_kernels.cu:256-261): WORD is the tally word a lane wants to bump (~0u: none). Lanes are served in slot
+// order and slots are filled in launch order, so photons that were launched into one column and came down (or
+// went up) side by side sit in neighbouring lanes: the first lane of a run of equal words adds the run's length
+// with one atomic. Executed by the whole wave (it votes).
+#define RT_SLAB_TALLY(WORD) \
+            { \
+                const uint32_t prev_word = (uint32_t)__shfl_up((int)(WORD), 1); \
+                const bool wants = (WORD) != 0xffffffffu; \
+                const bool leader = wants && (lane == 0 || prev_word != (WORD)); \
+                const unsigned long long lm = __ballot(leader || !wants); \
+                if (leader) \
+                { \
+                    const unsigned long long above = lane == 63 ? 0ull : lm >> (lane + 1); \
+                    const int run = above ? 1 + __builtin_ctzll(above) : 64 - lane; \
+                    tally_add(&a.tallies[(WORD)], (unsigned long long)run); \
+                } \
+            }
+
+template <int PHYS, bool STATS, int NS, bool HIER>
 __global__ void __launch_bounds__(kPoolBlock)
-rt_trace_pool_kernel(const TraceArgs a)
+rt_trace_pool_kernel(const PoolArgs a)
 {
     using namespace rt;
     static_assert(NS % 16 == 0 && NS >= 64 && NS <= 256, "pool size");
     constexpr int kHalves = (NS + 63) / 64;
+    constexpr bool PLANAR = PHYS == PHYS_PLANAR;
+    constexpr bool FIXED_DOT = PHYS == PHYS_FIXED_DOT;
     __shared__ __attribute__((aligned(16))) uint32_t lds[NS * kPoolRec + 16];
 
     const int lane = threadIdx.x;
@@ -769,6 +836,7 @@ rt_trace_pool_kernel(const TraceArgs a)
     uint32_t wave_left = 0;
     // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on; ranges of XCDs found empty so far
     uint32_t ranges_dry = 0;              // == kXcds: no photon ID is left anywhere
+    uint32_t round_ctr = 0;               // rounds of this wave: every kTickRounds-th is a tick of the step guard
 
     const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
 
@@ -779,10 +847,10 @@ rt_trace_pool_kernel(const TraceArgs a)
         stv[h] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
     int n_t = 0, n_e = 0, n_s = 0, n_x = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
     // photon ID words of the slots this lane owns (slot h * 64 + lane): {pid_lo, pid_hi | nev << 8}. Only the
-    // event and launch stages touch them; keeping them out of LDS is what lets 22 waves share a CU
-    uint32_t id_lo[kHalves], id_hn[kHalves], nst[kHalves];
+    // event and launch stages touch them; keeping them out of LDS is what lets 26 waves share a CU
+    uint32_t id_lo[kHalves], id_hn[kHalves];
 #pragma unroll
-    for (int h = 0; h < kHalves; ++h) { id_lo[h] = 0u; id_hn[h] = 0u; nst[h] = 0u; }
+    for (int h = 0; h < kHalves; ++h) { id_lo[h] = 0u; id_hn[h] = 0u; }
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
@@ -797,6 +865,9 @@ rt_trace_pool_kernel(const TraceArgs a)
             cls = 4u;
         if (n_l >= a.th_launch || n_t + n_e + n_s + n_x == 0)
             cls = 3u;
+        ++round_ctr;
+        const bool tick = (round_ctr & (kTickRounds - 1u)) == 0u;
+        const uint32_t age_inc = tick ? kAgeOne : 0u;
 
         // ---- gather up to 64 waiting slots into the lanes ----
         __builtin_amdgcn_s_setprio(RT_PRIO);
@@ -828,16 +899,6 @@ rt_trace_pool_kernel(const TraceArgs a)
 #define BPERM(LANE, V) (uint32_t)__builtin_amdgcn_ds_bpermute((int)((LANE) << 2), (int)(V))
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
         uint32_t out_lo = 0u, out_hn = 0u;   // its new ID words (event and launch stages)
-        uint32_t nstep = 0u;             // its step count (every stage but the event stage)
-        if (cls != 1u && cls != 3u)
-        {
-#pragma unroll
-            for (int h = 0; h < kHalves; ++h)
-            {
-                const uint32_t v = BPERM(slot & 63u, nst[h]);
-                if ((slot >> 6) == (uint32_t)h) nstep = v;
-            }
-        }
 
         if (cls == 2u)
         {
@@ -853,15 +914,13 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const uint32_t cicj = __float_as_uint(g1.w);
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
+                uint32_t age = cks & kAgeMask;
                 float2 mm_pre = make_float2(0.0f, 0.0f);
                 if (slab == a.gslab)
                     mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
                 __builtin_amdgcn_s_setprio(0);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
-                float sp = 0.0f, cp = 0.0f;
-                if (!a.planar)
-                    rt_sincos2pi(g2.z, sp, cp);
-                if (a.planar)
+                if (PLANAR)
                 {
                     // the 2D tracer's rules (raytracer.cpp:360-364, 280-282): turn the direction by
                     // +-acos(mu) within the x-z plane (angle-sum formulas instead of acos/atan2/sin/cos),
@@ -885,43 +944,48 @@ rt_trace_pool_kernel(const TraceArgs a)
                     }
                     uy = 0.0f;
                 }
-                else if (state == PS_SCATTER)
+                else
                 {
-                    // phase function + rotation, raytracer_kernels.cu:520-548
-                    const bool from_cloud = (cks >> 25) & 1u;
-                    const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
-                    const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
-                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                    const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
-                    if (fx < fy)
+                    float sp, cp;
+                    rt_sincos2pi(g2.z, sp, cp);
+                    if (state == PS_SCATTER)
                     {
-                        if (fx < fz) ax = 1.0f; else az = 1.0f;
+                        // phase function + rotation, raytracer_kernels.cu:520-548
+                        const bool from_cloud = (cks >> 25) & 1u;
+                        const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
+                        const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
+                        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                        const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
+                        if (fx < fy)
+                        {
+                            if (fx < fz) ax = 1.0f; else az = 1.0f;
+                        }
+                        else
+                        {
+                            if (fy < fz) ay = 1.0f; else az = 1.0f;
+                        }
+                        // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
+                        const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
+                                                     : fma_(az, az, fma_(ay, uy, ax * ux));
+                        float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
+                        const float inv_len = rt_rcp(rt_sqrt(fma_(oz, oz, fma_(oy, oy, ox * ox))));
+                        ox *= inv_len; oy *= inv_len; oz *= inv_len;
+                        const float bx = fma_(uy, oz, -(uz * oy));
+                        const float by = fma_(uz, ox, -(ux * oz));
+                        const float bz = fma_(ux, oy, -(uy * ox));
+                        const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
+                        const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
+                        const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
+                        ux = nx; uy = ny; uz = nz;
                     }
                     else
                     {
-                        if (fy < fz) ay = 1.0f; else az = 1.0f;
+                        // Lambertian reflection, raytracer_kernels.cu:467-473
+                        const float mu = rt_sqrt(g2.y);
+                        ux = mu * sp;
+                        uy = mu * cp;
+                        uz = rt_sqrt(fma_(-mu, mu, 1.0f) + RT_EPS);
                     }
-                    // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
-                    const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
-                                                 : fma_(az, az, fma_(ay, uy, ax * ux));
-                    float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
-                    const float inv_len = rt_rcp(rt_sqrt(fma_(oz, oz, fma_(oy, oy, ox * ox))));
-                    ox *= inv_len; oy *= inv_len; oz *= inv_len;
-                    const float bx = fma_(uy, oz, -(uz * oy));
-                    const float by = fma_(uz, ox, -(ux * oz));
-                    const float bz = fma_(ux, oy, -(uy * ox));
-                    const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
-                    const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
-                    const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
-                    ux = nx; uy = ny; uz = nz;
-                }
-                else
-                {
-                    // Lambertian reflection, raytracer_kernels.cu:467-473
-                    const float mu = rt_sqrt(g2.y);
-                    ux = mu * sp;
-                    uy = mu * cp;
-                    uz = rt_sqrt(fma_(-mu, mu, 1.0f) + RT_EPS);
                 }
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
@@ -936,7 +1000,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                     ns = PS_SLAB;
                 R4(0) = make_float4(x, y, z, tau);
                 R4(1) = make_float4(ux, uy, uz, __uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)));
-                R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24)));
+                R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24) | age));
             }
         }
         else if (cls == 1u)
@@ -1018,7 +1082,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 else
                 {
                     // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    if (u01(w.x) <= a.launch->albedo)
+                    if (u01(w.x) <= cold_of(a)->albedo)
                     {
                         tally_add(&a.tallies[4u * a.ncol + cell]);
                         RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
@@ -1033,13 +1097,13 @@ rt_trace_pool_kernel(const TraceArgs a)
         {
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
             __builtin_amdgcn_s_setprio(0);
-            const LaunchBlock* const lb = a.launch;
+            const ColdPtr cb = cold_of(a);
             while (__builtin_expect(wave_left == 0u && ranges_dry < (uint32_t)kXcds, 0))
             {
                 // next chunk of IDs from this XCD's range (or the next range that has any left): one
                 // returning atomic per chunk, broadcast from lane 0
-                const uint32_t chunk = lb->chunk;
-                const uint64_t total = lb->total, sub = lb->sub_size;
+                const uint32_t chunk = cb->chunk;
+                const uint64_t total = cb->total, sub = cb->sub_size;
                 const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
                 const uint32_t x = (xcc + ranges_dry) & (kXcds - 1);
                 const uint64_t sub_lo = (uint64_t)x * sub;
@@ -1057,7 +1121,7 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
                 else
                 {
-                    wave_next = lb->pid_begin + c0;
+                    wave_next = cb->pid_begin + c0;
                     wave_left = sub_hi - c0 < (uint64_t)chunk ? (uint32_t)(sub_hi - c0) : chunk;
                 }
             }
@@ -1065,14 +1129,17 @@ rt_trace_pool_kernel(const TraceArgs a)
             if (active && ranges_dry < (uint32_t)kXcds)
                 ns = PS_LAUNCH;          // no ID left in this chunk: wait for the next one
             uint32_t toa_col = 0xffffffffu;
+            uint32_t tally_word = 0xffffffffu;      // surface / domain-top tally of the fused first step
             if (go)
             {
                 const uint64_t my_pid = wave_next + (uint64_t)lane;
                 const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
-                const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, 0u, key0, key1);
+                uint32_t lk0 = key0, lk1 = key1;            // see the event stage: no hoisted, spilled round keys
+                asm volatile("" : "+s"(lk0), "+s"(lk1));
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, 0u, 0u, lk0, lk1);
                 float tau_new = free_path_tau(u01(w.z));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
-                const int log2k = lb->launch_log2k;
+                const int log2k = cb->launch_log2k;
                 float x, y;
                 if (log2k < 0)
                 {
@@ -1081,19 +1148,19 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
                 else
                 {
-                    const uint32_t c = launch_column_index_exact(log2k, a.ncol, my_pid, key0, key1);
+                    const uint32_t c = launch_column_index_exact(log2k, a.ncol, my_pid, lk0, lk1);
                     uint32_t ic, jc;
-                    launch_column(lb->div_itot_mul, lb->div_itot_shift, (uint32_t)a.itot, c, ic, jc);
-                    const float dx = lb->dx, dy = lb->dy;
+                    launch_column(cb->div_itot_mul, cb->div_itot_shift, (uint32_t)a.itot, c, ic, jc);
+                    const float dx = cb->dx, dy = cb->dy;
                     x = fma_(u01(w.x), dx, (float)ic * dx);
                     y = fma_(u01(w.y), dy, (float)jc * dy);
                 }
                 const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
                 toa_col = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
-                int slab = a.nslab - 1;
-                float z = lb->ztop, tau = tau_new;
-                const float sun_x = lb->sun_x, sun_y = lb->sun_y, sun_z = lb->sun_z, iz = lb->inv_sun_z;
-                uint32_t cicj = 0u, ck = 0u;
+                int slab = cb->nslab - 1;
+                float z = cb->ztop, tau = tau_new;
+                const float sun_x = cb->sun_x, sun_y = cb->sun_y, sun_z = cb->sun_z, iz = cb->inv_sun_z;
+                uint32_t cicj = 0u, ck = 0u, age = 0u;
                 if (slab == a.gslab)
                 {
                     cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16);
@@ -1112,8 +1179,8 @@ rt_trace_pool_kernel(const TraceArgs a)
                 }
                 R4(0) = make_float4(x, y, z, tau);
                 R4(1) = make_float4(sun_x, sun_y, sun_z, __uint_as_float(cicj));
-                R4(2) = make_float4(lb->inv_sun_x, lb->inv_sun_y, iz,
-                                    __uint_as_float(ck | (((uint32_t)slab & 0xffu) << 16) | (ns == PS_SURFACE ? 1u << 26 : 0u)));
+                R4(2) = make_float4(cb->inv_sun_x, cb->inv_sun_y, iz,
+                                    __uint_as_float(ck | (((uint32_t)slab & 0xffu) << 16) | (ns == PS_SURFACE ? 1u << 26 : 0u) | age));
                 out_lo = pid_lo;
                 out_hn = pid_hi | (1u << 8);
             }
@@ -1131,6 +1198,9 @@ rt_trace_pool_kernel(const TraceArgs a)
                     tally_add(&a.tallies[toa_col], (unsigned long long)(next - lane));
                 }
             }
+#if RT_FUSE_LAUNCH
+            RT_SLAB_TALLY(tally_word)
+#endif
             // advance the wave's ID cursor by the lanes served
             const uint32_t adv = (uint32_t)n < wave_left ? (uint32_t)n : wave_left;
             wave_next += adv;
@@ -1141,6 +1211,8 @@ rt_trace_pool_kernel(const TraceArgs a)
             // ---- slab stage: everything outside the grid ----
             __builtin_amdgcn_s_setprio(0);
             if (STATS) { ++rounds_x; lanes_x += n; }
+            const ColdPtr cb = cold_of(a);
+            uint32_t tally_word = 0xffffffffu;
             if (active)
             {
                 const float4 g0 = R4(0);
@@ -1150,13 +1222,14 @@ rt_trace_pool_kernel(const TraceArgs a)
                 float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
                 int slab = (int)(int8_t)((cks >> 16) & 0xffu);
                 const bool up = iz > 0.0f;
-                uint32_t cicj = 0u, ck = cks & 0xffffu;
+                uint32_t cicj = 0u, ck = cks & 0xffffu, age = cks & kAgeMask;
                 RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
                 R4(0) = make_float4(x, y, z, tau);
                 if (ns == PS_TRAVERSE)
                     RW(7) = cicj;
-                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u);
+                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u) | age;
             }
+            RT_SLAB_TALLY(tally_word)
         }
         else
         {
@@ -1171,31 +1244,31 @@ rt_trace_pool_kernel(const TraceArgs a)
                 const float ux = g1.x, uy = g1.y, uz = g1.z;
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
+                uint32_t age = cks & kAgeMask;
                 ns = PS_TRAVERSE;
                 RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
+#if RT_T_STEPS > 1
+#pragma unroll
+                for (int extra = 1; extra < RT_T_STEPS; ++extra)
+                    if (ns == PS_TRAVERSE)
+                    {
+                        RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
+                    }
+#endif
                 R4(0) = make_float4(x, y, z, tau);
                 RW(7) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24));
+                RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | age;
             }
         }
 
 #undef R4
 #undef RW
-        // ---- the owners of the served slots take the new ID words from the lanes that served them ----
+        // ---- the owners of the served slots take the new state and ID words from the lanes that served them ----
 #pragma unroll
         for (int h = 0; h < kHalves; ++h)
         {
             const uint32_t v = BPERM((uint32_t)srv[h] & 63u, ns);
             if (srv[h] >= 0) stv[h] = v;
-        }
-        if (cls != 1u)
-        {
-#pragma unroll
-            for (int h = 0; h < kHalves; ++h)
-            {
-                const uint32_t v = BPERM((uint32_t)srv[h] & 63u, nstep);
-                if (srv[h] >= 0) nst[h] = v;
-            }
         }
         if (cls == 1u || cls == 3u)
         {
@@ -1228,18 +1301,19 @@ rt_trace_pool_kernel(const TraceArgs a)
 
     if (STATS)
     {
+        unsigned long long* const events = cold_of(a)->events;
         const uint32_t ev[9] = {ev_step, ev_coll, ev_real, ev_scat, ev_cscat, ev_sfc, ev_toa, ev_abs, ev_trans};
 #pragma unroll
         for (int e = 0; e < 9; ++e)
             if (ev[e])
-                __hip_atomic_fetch_add(&(a.cursor - kCursorWord)[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&events[e], (unsigned long long)ev[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0)
         {
             const uint32_t sch[8] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s, rounds_x, lanes_x};
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                __hip_atomic_fetch_add(&(a.cursor - kCursorWord)[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&events[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1322,7 +1396,7 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
 }
 
 // Stores the launch block of the next pool launch and rewinds the ID cursors, in stream order.
-__global__ void rt_launch_block_kernel(LaunchBlock* dst, const LaunchBlock src, unsigned long long* cursor)
+__global__ void rt_launch_block_kernel(ColdBlock* dst, const ColdBlock src, unsigned long long* cursor)
 {
     if (blockIdx.x != 0)
         return;
@@ -1416,7 +1490,7 @@ struct rt_context
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
-    LaunchBlock* d_launch = nullptr;
+    ColdBlock* d_cold = nullptr;
 
     bool have_optics = false, have_scene = false;
     std::vector<float> lev_max;
@@ -1437,6 +1511,13 @@ namespace
 // Slabs from the per-level reductions: cloud layer = levels k_lo..k_hi holding any asy > 0
 // (cloud_mask_kernel, raytracer_kernels.cu:263-305, without its indexing bugs); majorant of a
 // slab = max of gas + cloud over its levels (raytracer_3d_io.cu:60-77 takes it over the domain).
+// 1/M as the tables hold it: finite (FLT_MAX where M is 0 or, with a region level packed into its low bits, a
+// denormal), so that the traverse step's tau * (1/M) is a number for tau == 0 too; the CPU checker holds the same function
+inline float majorant_reciprocal(float m)
+{
+    return std::fmin(1.0f / m, FLT_MAX);
+}
+
 void build_slabs(rt_context* c)
 {
     int k_lo = -1, k_hi = -1;
@@ -1460,7 +1541,7 @@ void build_slabs(rt_context* c)
         float m = 0.0f;
         for (int k = lo[i]; k < hi[i]; ++k) m = c->lev_max[k] > m ? c->lev_max[k] : m;
         s.kmaj[i] = m;
-        c->inv_kmaj[i] = 1.0f / m;
+        c->inv_kmaj[i] = majorant_reciprocal(m);
         s.zface[i] = (float)lo[i] * c->dz;
     }
     s.zface[n] = (float)c->ktot * c->dz;
@@ -1509,7 +1590,7 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
                             {
                                 const size_t e = ((size_t)k * ncj + j) * nci + i;
                                 lvl[e] = (uint8_t)L;
-                                maj[e] = make_float2(m, 1.0f / m);
+                                maj[e] = make_float2(m, majorant_reciprocal(m));
                             }
                 }
     }
@@ -1522,7 +1603,7 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
         memcpy(&bits, &maj[e].x, 4);
         bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
         memcpy(&maj[e].x, &bits, 4);
-        maj[e].y = 1.0f / maj[e].x;
+        maj[e].y = majorant_reciprocal(maj[e].x);
     }
 }
 
@@ -1633,6 +1714,180 @@ int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, co
 }
 } // namespace
 
+namespace
+{
+// Launches the tracer for photon IDs [pid_begin, pid_begin + count).
+int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
+{
+    const char* const who = "rt_trace";
+    if (!c) return fail(RT_ERR_ARG, "%s: null context", who);
+    if (!c->have_optics || !c->have_scene)
+        return fail(RT_ERR_STATE, "%s: call rt_upload_optics and rt_set_scene first", who);
+    if (pid_begin + count < pid_begin) return fail(RT_ERR_ARG, "%s: photon id range overflows 64 bits", who);
+    // every refusal comes before anything is enqueued or any state of the context changes
+    if (c->planar && c->pool == 0)
+        return fail(RT_ERR_ARG, "%s: option planar needs the pool kernel (pool > 0)", who);
+    if (c->pool > 0 && count > 0 && pid_begin + count > (1ull << 40))
+        return fail(RT_ERR_ARG, "%s: the pool kernel packs photon ids into 40 bits (ids up to 2^40; option pool = 0 "
+                                "carries 64-bit ids)", who);
+    RT_HIP(hipSetDevice(c->device));
+    if (count == 0) { c->timed = false; return RT_OK; }
+    if (c->maj_dirty)
+    {
+        const int rc = build_majorants(c);
+        if (rc != RT_OK) return rc;
+    }
+
+    const rt_slab_info& sl = c->slabs;
+    const float xs = (float)c->itot * c->dx, ys = (float)c->jtot * c->dy;
+    const auto rcp = [](float u) { return std::fmin(std::fmax(1.0f / u, -FLT_MAX), FLT_MAX); };   // dir_reciprocal
+    // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
+    uint32_t div_shift, div_mul;
+    {
+        int l = 0;
+        while ((1u << l) < (uint32_t)c->itot) ++l;
+        div_shift = 31u + (uint32_t)l;
+        div_mul = (uint32_t)(((1ull << div_shift) / (uint64_t)c->itot) + 1ull);
+    }
+    const bool gridded = sl.gslab >= 0;
+
+    RT_HIP(hipEventRecord(c->ev_start, c->stream));
+    if (c->pool > 0)
+    {
+        // pool kernel: one wave per workgroup; LDS bounds the resident waves (160 KiB per CU)
+        const int ns = c->pool;
+        const size_t lds_bytes = ((size_t)ns * kPoolRec + 16) * 4;
+        int per_cu = (int)((160u * 1024u) / lds_bytes);
+        if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
+        if (per_cu < 1) per_cu = 1;
+        const uint64_t pcap = (uint64_t)c->cu_count * per_cu;
+        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
+        // every resident wave still finds work
+        uint32_t chunk = (uint32_t)c->chunk;
+        while (chunk > 64u && count / chunk < 4u * pcap) chunk >>= 1;
+
+        unsigned long long* cursor = c->d_events + kCursorWord;
+        ColdBlock* d_cold = c->d_cold;
+        ColdBlock cb;
+        memset(&cb, 0, sizeof(cb));
+        cb.pid_begin = pid_begin; cb.total = count;
+        cb.sub_size = (((count + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
+        cb.events = c->d_events;
+        cb.chunk = chunk; cb.launch_log2k = c->launch_log2k;
+        cb.sun_x = sl.sun[0]; cb.sun_y = sl.sun[1]; cb.sun_z = sl.sun[2];
+        cb.inv_sun_x = rcp(cb.sun_x); cb.inv_sun_y = rcp(cb.sun_y); cb.inv_sun_z = rcp(cb.sun_z);
+        cb.ztop = sl.zface[sl.nslab]; cb.dx = c->dx; cb.dy = c->dy; cb.albedo = c->albedo;
+        cb.div_itot_mul = div_mul; cb.div_itot_shift = div_shift;
+        for (int i = 0; i < 4; ++i) cb.zface[i] = sl.zface[i];
+        cb.inv_xs = 1.0f / xs; cb.inv_ys = 1.0f / ys;
+        cb.ncoarse = (uint32_t)c->ncoarse; cb.nslab = sl.nslab;
+
+        PoolArgs a;
+        a.cells = c->d_cells; a.maj = c->d_maj; a.tallies = c->d_tallies;
+        a.cold = d_cold; a.cursor = cursor;
+        a.seed = seed;
+        a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot; a.ncol = (uint32_t)c->ncol;
+        a.gslab = sl.gslab; a.nci = sl.nci; a.ncj = sl.ncj; a.nck = sl.nck;
+        a.th_launch = c->th_launch;
+        a.xs = xs; a.ys = ys;
+        a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
+        a.hx = sl.hx; a.hy = sl.hy; a.hz = sl.hz;
+        a.inv_hx = gridded ? 1.0f / a.hx : 0.0f; a.inv_hy = gridded ? 1.0f / a.hy : 0.0f;
+        a.inv_hz = gridded ? 1.0f / a.hz : 0.0f;
+        a.zc0 = gridded ? sl.zface[sl.gslab] : 0.0f; a.zc1 = gridded ? sl.zface[sl.gslab + 1] : 0.0f;
+
+        // the cold block and the rewound cursors, in stream order ahead of the tracer
+        hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, d_cold, cb, cursor);
+        uint64_t pblocks = (count + chunk - 1) / chunk;
+        if (pblocks > pcap) pblocks = pcap;
+        const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
+        const int phys = c->planar ? PHYS_PLANAR : (c->fixed_dot ? PHYS_FIXED_DOT : PHYS_COMPAT);
+        // NS = 128 is the tuned default and comes with and without the event counters; the other pool sizes exist
+        // for experiments and tests and always count
+#define RT_LAUNCH_POOL_PS(P, S, NS, H) hipLaunchKernelGGL((rt_trace_pool_kernel<P, S, NS, H>), grid, pblock, 0, c->stream, a)
+#define RT_LAUNCH_POOL_P(P, NS, H)                                                                             \
+        do {                                                                                                   \
+            if (NS != 128 || c->stats) RT_LAUNCH_POOL_PS(P, true, NS, H);                                      \
+            else RT_LAUNCH_POOL_PS(P, (NS != 128), NS, H);                                                     \
+        } while (0)
+#define RT_LAUNCH_POOL_H(NS, H)                                                                                \
+        do {                                                                                                   \
+            if (phys == PHYS_PLANAR) RT_LAUNCH_POOL_P(PHYS_PLANAR, NS, H);                                     \
+            else if (phys == PHYS_FIXED_DOT) RT_LAUNCH_POOL_P(PHYS_FIXED_DOT, NS, H);                          \
+            else RT_LAUNCH_POOL_P(PHYS_COMPAT, NS, H);                                                         \
+        } while (0)
+#define RT_LAUNCH_POOL(NS)                                                                                     \
+        do {                                                                                                   \
+            if (c->hier) RT_LAUNCH_POOL_H(NS, true); else RT_LAUNCH_POOL_H(NS, false);                         \
+        } while (0)
+        switch (ns)
+        {
+            case 128: RT_LAUNCH_POOL(128); break;
+#ifndef RT_ONLY_DEFAULT_POOL
+            case 64: RT_LAUNCH_POOL(64); break;
+            case 96: RT_LAUNCH_POOL(96); break;
+            case 160: RT_LAUNCH_POOL(160); break;
+            case 192: RT_LAUNCH_POOL(192); break;
+            case 256: RT_LAUNCH_POOL(256); break;
+#endif
+            default: return fail(RT_ERR_ARG, "%s: pool size %d is not in this build", who, ns);
+        }
+#undef RT_LAUNCH_POOL
+#undef RT_LAUNCH_POOL_H
+#undef RT_LAUNCH_POOL_P
+#undef RT_LAUNCH_POOL_PS
+    }
+    else
+    {
+        TraceArgs a;
+        a.cells = c->d_cells;
+        a.tallies = c->d_tallies; a.events = c->d_events;
+        a.seed = seed; a.pid_begin = pid_begin; a.pid_end = pid_begin + count;
+        a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot;
+        a.ncol = (uint32_t)c->ncol; a.ncell = (uint32_t)c->ncell;
+        a.xs = xs; a.ys = ys;
+        a.inv_xs = 1.0f / a.xs; a.inv_ys = 1.0f / a.ys;
+        a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
+        a.albedo = c->albedo;
+        a.sun_x = sl.sun[0]; a.sun_y = sl.sun[1]; a.sun_z = sl.sun[2];
+        a.inv_sun_x = rcp(a.sun_x); a.inv_sun_y = rcp(a.sun_y); a.inv_sun_z = rcp(a.sun_z);
+        a.nslab = sl.nslab;
+        for (int i = 0; i < 4; ++i) a.zface[i] = sl.zface[i];
+        a.maj = c->d_maj;
+        a.gslab = sl.gslab;
+        a.nci = sl.nci; a.ncj = sl.ncj; a.nck = sl.nck;
+        a.ncoarse = (uint32_t)c->ncoarse;
+        a.hx = sl.hx; a.hy = sl.hy; a.hz = sl.hz;
+        a.inv_hx = gridded ? 1.0f / a.hx : 0.0f; a.inv_hy = gridded ? 1.0f / a.hy : 0.0f;
+        a.inv_hz = gridded ? 1.0f / a.hz : 0.0f;
+        a.zc0 = gridded ? a.zface[a.gslab] : 0.0f; a.zc1 = gridded ? a.zface[a.gslab + 1] : 0.0f;
+        a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
+        a.launch_log2k = c->launch_log2k;
+        a.dx = c->dx; a.dy = c->dy;
+        a.div_itot_mul = div_mul; a.div_itot_shift = div_shift;
+
+        uint64_t blocks = (count + kBlock - 1) / kBlock;
+        const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+        const dim3 grid((unsigned)blocks), block(kBlock);
+        if (c->fixed_dot)
+        {
+            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
+            else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
+        }
+        else
+        {
+            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
+            else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+        }
+    }
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+} // namespace
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_last_error.c_str(); }
@@ -1672,7 +1927,7 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
     if (e == hipSuccess) e = hipMalloc(&c->d_cells, sizeof(float4) * ncell);
     if (e == hipSuccess) e = hipMalloc(&c->d_tallies, sizeof(unsigned long long) * c->nwords);
     if (e == hipSuccess) e = hipMalloc(&c->d_events, sizeof(unsigned long long) * kEventWords);
-    if (e == hipSuccess) e = hipMalloc(&c->d_launch, sizeof(LaunchBlock));
+    if (e == hipSuccess) e = hipMalloc(&c->d_cold, sizeof(ColdBlock));
     if (e == hipSuccess) e = hipMemset(c->d_tallies, 0, sizeof(unsigned long long) * c->nwords);
     if (e == hipSuccess) e = hipMemset(c->d_events, 0, sizeof(unsigned long long) * kEventWords);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
@@ -1698,7 +1953,7 @@ int rt_destroy(rt_context* c)
     if (c->d_lvl) (void)hipFree(c->d_lvl);
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
-    if (c->d_launch) (void)hipFree(c->d_launch);
+    if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -1821,134 +2076,19 @@ int rt_set_stream(rt_context* c, void* hip_stream)
 
 int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
 {
-    if (!c) return fail(RT_ERR_ARG, "rt_trace: null context");
-    if (!c->have_optics || !c->have_scene)
-        return fail(RT_ERR_STATE, "rt_trace: call rt_upload_optics and rt_set_scene first");
-    if (pid_begin + count < pid_begin) return fail(RT_ERR_ARG, "rt_trace: photon id range overflows 64 bits");
+    return trace_impl(c, seed, pid_begin, count);
+}
+
+int rt_prepare(rt_context* c)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_prepare: null context");
+    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_prepare: call rt_upload_optics first");
     RT_HIP(hipSetDevice(c->device));
-    if (count == 0) { c->timed = false; return RT_OK; }
     if (c->maj_dirty)
     {
         const int rc = build_majorants(c);
         if (rc != RT_OK) return rc;
     }
-
-    TraceArgs a;
-    a.cells = c->d_cells;
-    a.tallies = c->d_tallies; a.events = c->d_events;
-    a.seed = seed; a.pid_begin = pid_begin; a.pid_end = pid_begin + count;
-    a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot;
-    a.ncol = (uint32_t)c->ncol; a.ncell = (uint32_t)c->ncell;
-    a.xs = (float)c->itot * c->dx; a.ys = (float)c->jtot * c->dy;
-    a.inv_xs = 1.0f / a.xs; a.inv_ys = 1.0f / a.ys;
-    a.inv_dx = 1.0f / c->dx; a.inv_dy = 1.0f / c->dy; a.inv_dz = 1.0f / c->dz;
-    a.albedo = c->albedo;
-    a.sun_x = c->slabs.sun[0]; a.sun_y = c->slabs.sun[1]; a.sun_z = c->slabs.sun[2];
-    {
-        const auto rcp = [](float u) { return std::fmin(std::fmax(1.0f / u, -FLT_MAX), FLT_MAX); };   // dir_reciprocal
-        a.inv_sun_x = rcp(a.sun_x); a.inv_sun_y = rcp(a.sun_y); a.inv_sun_z = rcp(a.sun_z);
-    }
-    a.nslab = c->slabs.nslab;
-    for (int i = 0; i < 4; ++i) a.zface[i] = c->slabs.zface[i];
-    a.maj = c->d_maj;
-    a.gslab = c->slabs.gslab;
-    a.nci = c->slabs.nci; a.ncj = c->slabs.ncj; a.nck = c->slabs.nck;
-    a.ncoarse = (uint32_t)c->ncoarse;
-    a.hx = c->slabs.hx; a.hy = c->slabs.hy; a.hz = c->slabs.hz;
-    a.inv_hx = a.gslab >= 0 ? 1.0f / a.hx : 0.0f; a.inv_hy = a.gslab >= 0 ? 1.0f / a.hy : 0.0f;
-    a.inv_hz = a.gslab >= 0 ? 1.0f / a.hz : 0.0f;
-    a.zc0 = a.gslab >= 0 ? a.zface[a.gslab] : 0.0f; a.zc1 = a.gslab >= 0 ? a.zface[a.gslab + 1] : 0.0f;
-    a.th_event = c->th_event; a.th_scatter = c->th_scatter; a.low_traverse = c->low_traverse;
-    a.th_launch = c->th_launch;
-    a.launch_log2k = c->launch_log2k;
-    a.planar = c->planar ? 1 : 0;
-    if (c->planar && c->pool == 0)
-        return fail(RT_ERR_ARG, "rt_trace: option planar needs the pool kernel (pool > 0)");
-    a.dx = c->dx; a.dy = c->dy;
-    {
-        // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
-        int l = 0;
-        while ((1u << l) < (uint32_t)c->itot) ++l;
-        a.div_itot_shift = 31u + (uint32_t)l;
-        a.div_itot_mul = (uint32_t)(((1ull << a.div_itot_shift) / (uint64_t)c->itot) + 1ull);
-    }
-
-    uint64_t blocks = (count + kBlock - 1) / kBlock;
-    const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
-    if (blocks > cap) blocks = cap;
-
-    RT_HIP(hipEventRecord(c->ev_start, c->stream));
-    const dim3 block(kBlock);
-    if (c->pool > 0)
-    {
-        // pool kernel: one wave per workgroup; LDS bounds the resident waves (160 KiB per CU)
-        const int ns = c->pool;
-        if (a.pid_end > (1ull << 40))
-            return fail(RT_ERR_ARG, "rt_trace: the pool kernel packs photon ids into 40 bits");
-        const size_t lds_bytes = ((size_t)ns * kPoolRec + 16) * 4;
-        int per_cu = (int)((160u * 1024u) / lds_bytes);
-        if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
-        if (per_cu < 1) per_cu = 1;
-        const uint64_t pcap = (uint64_t)c->cu_count * per_cu;
-        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
-        // every resident wave still finds work
-        uint32_t chunk = (uint32_t)c->chunk;
-        while (chunk > 64u && count / chunk < 4u * pcap) chunk >>= 1;
-        LaunchBlock lb;
-        memset(&lb, 0, sizeof(lb));
-        lb.pid_begin = pid_begin; lb.total = count;
-        lb.sub_size = (((count + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
-        lb.chunk = chunk; lb.launch_log2k = c->launch_log2k;
-        lb.sun_x = a.sun_x; lb.sun_y = a.sun_y; lb.sun_z = a.sun_z;
-        lb.inv_sun_x = a.inv_sun_x; lb.inv_sun_y = a.inv_sun_y; lb.inv_sun_z = a.inv_sun_z;
-        lb.ztop = a.zface[a.nslab]; lb.dx = a.dx; lb.dy = a.dy; lb.albedo = a.albedo;
-        lb.div_itot_mul = a.div_itot_mul; lb.div_itot_shift = a.div_itot_shift;
-        a.launch = c->d_launch;
-        a.cursor = c->d_events + kCursorWord;
-        hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, c->d_launch, lb, a.cursor);
-        uint64_t pblocks = (count + chunk - 1) / chunk;
-        if (pblocks > pcap) pblocks = pcap;
-        const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
-#define RT_LAUNCH_POOL_H(NS, H)                                                                                    \
-        do {                                                                                                       \
-            if (c->fixed_dot) { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<true, true, NS, H>), grid, pblock, 0, c->stream, a);   \
-                                else hipLaunchKernelGGL((rt_trace_pool_kernel<true, false, NS, H>), grid, pblock, 0, c->stream, a); }        \
-            else { if (c->stats) hipLaunchKernelGGL((rt_trace_pool_kernel<false, true, NS, H>), grid, pblock, 0, c->stream, a);              \
-                   else hipLaunchKernelGGL((rt_trace_pool_kernel<false, false, NS, H>), grid, pblock, 0, c->stream, a); }                    \
-        } while (0)
-#define RT_LAUNCH_POOL(NS)                                                                                         \
-        do {                                                                                                       \
-            if (c->hier) RT_LAUNCH_POOL_H(NS, true); else RT_LAUNCH_POOL_H(NS, false);                                 \
-        } while (0)
-        switch (ns)
-        {
-            case 64: RT_LAUNCH_POOL(64); break;
-            case 96: RT_LAUNCH_POOL(96); break;
-            case 128: RT_LAUNCH_POOL(128); break;
-            case 160: RT_LAUNCH_POOL(160); break;
-            case 192: RT_LAUNCH_POOL(192); break;
-            default: RT_LAUNCH_POOL(256); break;
-        }
-#undef RT_LAUNCH_POOL
-#undef RT_LAUNCH_POOL_H
-    }
-    else
-    {
-        const dim3 grid((unsigned)blocks);
-        if (c->fixed_dot)
-        {
-            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
-            else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
-        }
-        else
-        {
-            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
-            else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
-        }
-    }
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipEventRecord(c->ev_stop, c->stream));
-    c->timed = true;
     return RT_OK;
 }
 
@@ -2031,8 +2171,13 @@ int rt_bind_tally_buffer(rt_context* c, void* ptr, size_t n_words)
         return fail(RT_ERR_ARG, "rt_bind_tally_buffer: buffer has %zu words, the grid needs %zu", n_words, c->nwords);
     if (((uintptr_t)ptr & 7u) != 0) return fail(RT_ERR_ARG, "rt_bind_tally_buffer: buffer not 8-byte aligned");
     RT_HIP(hipSetDevice(c->device));
-    RT_HIP(hipStreamSynchronize(c->stream));
-    if (c->owns_tallies && c->d_tallies) RT_HIP(hipFree(c->d_tallies));
+    // The buffer is a kernel argument, so the switch is in stream order by itself: launches already enqueued keep
+    // the old pointer. Only a buffer the context owns has to be idle before it is freed.
+    if (c->owns_tallies && c->d_tallies)
+    {
+        RT_HIP(hipStreamSynchronize(c->stream));
+        RT_HIP(hipFree(c->d_tallies));
+    }
     c->d_tallies = (unsigned long long*)ptr;
     c->owns_tallies = false;
     return RT_OK;

@@ -58,6 +58,7 @@ def load_library():
         "rt_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
         "rt_set_stream": (C.c_int, [vp, vp]),
         "rt_trace": (C.c_int, [vp, u64, u64, u64]),
+        "rt_prepare": (C.c_int, [vp]),
         "rt_synchronize": (C.c_int, [vp]),
         "rt_download_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
         "rt_upload_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
@@ -151,6 +152,10 @@ class PhotonTracer:
     # -- the hot path -----------------------------------------------------------------------
     def trace(self, seed, photon_id_begin, photon_count):
         _check(self.lib.rt_trace(self._h, int(seed), int(photon_id_begin), int(photon_count)))
+
+    def prepare(self):
+        """Build the majorant tables now, so that later trace() calls are pure asynchronous launches."""
+        _check(self.lib.rt_prepare(self._h))
 
     def synchronize(self):
         _check(self.lib.rt_synchronize(self._h))

@@ -309,6 +309,56 @@ def test_regression_zero_direction_component(rt):
     assert tr.events() == ev and ev["abort"] == 0 and ev["steps"] < 100
 
 
+ZERO_TAU_PIDS = (17591041, 79261592, 79468374, 86667682)     # seed 5: the launch draw gives tau == 0 exactly
+
+
+def gas_free_scene(S):
+    """No gas at all and clouds that reach the domain top: photons are launched straight into the supervoxel
+    grid, whose cloud-free parts merge into regions with majorant 0."""
+    return S.cumulus(24, 20, 12, 80.0, 80.0, 50.0, n_clouds=6, seed=6, z_base=300.0, z_top=600.0, k_gas=0.0)
+
+
+@pytest.mark.parametrize("pool", [0, 128])
+def test_regression_zero_majorant_region_with_zero_optical_depth(rt, pool):
+    """A merged region without extinction has M = 0 with the region level in its low mantissa bits (a denormal)
+    and once had 1/M = +inf in the table: a photon entering it with tau == 0 (one launch in 2^24) computed
+    0 * inf = NaN and was 'absorbed' in cell 0. 1/M is finite now (FLT_MAX): such a photon takes a null collision
+    where it stands and goes on. The four photons below draw tau == 0 at launch."""
+    scene = gas_free_scene(rt.scenes)
+    kw = dict(supergrid=(2, 2, 1), levels=3, merge_tau=2.0)
+    osl = O.oracle_slabs(scene, **kw)
+    assert osl.gslab == osl.nslab - 1 and int(osl.lvl_array.max()) >= 1            # launched into merged regions
+    assert np.isfinite(osl.maj_array).all() and float(osl.maj_array[..., 1].max()) == np.finfo(np.float32).max
+    ol = O.lib()
+    for pid in ZERO_TAU_PIDS:
+        w = (C.c_uint32 * 4)()
+        ol.oracle_philox4x32_10((C.c_uint32 * 4)(pid & 0xffffffff, pid >> 32, 0, 0), (C.c_uint32 * 2)(5, 0), w)
+        assert w[2] >> 8 == 0
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=3, merge_tau_milli=2000)
+    tr.set_supergrid(2, 2, 1)
+    want = O.new_tallies(scene)
+    ev_want = dict.fromkeys(O.EVENT_NAMES, 0)
+    for pid in ZERO_TAU_PIDS:
+        tr.trace(5, pid, 1)
+        _, ev = O.photon_oracle(scene, 5, pid, 1, tallies=want, **kw)
+        ev_want = {k: ev_want[k] + ev[k] for k in ev}
+    tr.synchronize()                    # raises if a photon was abandoned
+    got = tr.tallies()
+    _assert_same(got, want)
+    assert tr.events() == ev_want and ev_want["abort"] == 0
+    assert rt.photon_balance(got) == 0 and int(got["toa_down"].sum()) == len(ZERO_TAU_PIDS)
+    empty = (scene.k_gas + scene.k_cloud) == 0
+    assert int(got["atmos_direct"][empty].sum()) + int(got["atmos_diffuse"][empty].sum()) == 0
+    # and a whole batch through the gas-free scene: nothing abandoned, nothing absorbed where nothing absorbs
+    tr.reset()
+    tr.trace(5, 0, 1 << 18); tr.synchronize()
+    got = tr.tallies()
+    want, _ = O.photon_oracle(scene, 5, 0, 1 << 18, **kw)
+    _assert_same(got, want)
+    assert int(got["atmos_direct"][empty].sum()) + int(got["atmos_diffuse"][empty].sum()) == 0
+    tr.close()
+
+
 def test_errors_are_reported_not_fatal(rt):
     with pytest.raises(rt.RtError):
         rt.PhotonTracer(0, 4, 4, 1.0, 1.0, 1.0)
