@@ -164,6 +164,19 @@ int rt_trace(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t 
  * launch. Part of what cloud_mask_kernel's launch stands for (raytracer_3d.cu:116-130). */
 int rt_prepare(rt_context* ctx);
 
+/* rt_trace for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. It has NO counterpart in the reference. Same arguments, same results (bit for
+ * bit) and the same asynchronous launch on the context's stream as rt_trace, but it calls no hipMalloc, hipFree
+ * or any other allocating routine: the device words the pool kernel needs beyond its inputs and outputs -- the
+ * eight photon-ID cursors and the launch's cold block -- are taken from a 2 KiB static device array of the
+ * library instead of the context's allocation, and the call records no timing events. Limits, refused with
+ * RT_ERR_ARG / RT_ERR_STATE and a message instead of allocating: the context must use the pool kernel (option
+ * "pool" > 0), photon ids end at 2^40, and the majorant tables must already exist (rt_prepare after the last
+ * rt_upload_optics / option change). Every GPU holds ONE such array, shared by all contexts on it: calls of
+ * rt_trace_noalloc that overlap on one GPU (two streams, two threads) race on it; calls on one stream, or
+ * separated by rt_synchronize, do not. rt_trace itself is unaffected and may overlap with it. */
+int rt_trace_noalloc(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t photon_count);
+
 /* Blocks until the context's stream is idle (cudaDeviceSynchronize at raytracer_3d.cu:165) and
  * reports RT_ERR_ABORTED (once) if any photon hit the step guard since the last call. */
 int rt_synchronize(rt_context* ctx);

@@ -27,8 +27,15 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
+
+// Scratch of rt_trace_noalloc (the one entry point that allocates nothing, see include/rt_photon.h): the
+// photon-ID cursors and the cold block of a pool launch, 2 KiB per GPU, held until the process ends. In host code
+// this name is only a stand-in for the symbol: the address on each device comes from hipGetSymbolAddress
+// (scratch_of_device below) and only that pointer is ever handed to a kernel or a memset.
+static __device__ __align__(256) unsigned long long scratch[256];
 
 namespace
 {
@@ -70,6 +77,11 @@ constexpr int kCursorWord = 32;
 constexpr int kCursorStride = 16;     // words between the cursors of two XCDs: a 128-byte line each
 constexpr int kXcds = 8;
 constexpr int kEventWords = kCursorWord + kXcds * kCursorStride;
+// words of the static scratch of rt_trace_noalloc: the eight cursors (a 128-byte line each), then the cold block
+constexpr int kScratchWords = 256;
+constexpr int kScratchColdWord = kXcds * kCursorStride;
+constexpr int kMaxDevices = 64;
+
 // ------------------------------------------------------------------------------------------
 // Kernel arguments of the lane-resident tracer (by value: they live in SGPRs).
 struct TraceArgs
@@ -1716,10 +1728,34 @@ int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, co
 
 namespace
 {
-// Launches the tracer for photon IDs [pid_begin, pid_begin + count).
-int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
+// The device address of the static scratch on `device`, resolved once per device with that device current
+// (each GPU holds its own copy of the array at its own address).
+std::mutex g_scratch_mutex;
+unsigned long long* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_of_device(int device, unsigned long long** out)
 {
-    const char* const who = "rt_trace";
+    if (device < 0 || device >= kMaxDevices)
+        return fail(RT_ERR_ARG, "device %d beyond the %d devices the static scratch table covers", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device])
+    {
+        static_assert(sizeof(scratch) == sizeof(unsigned long long) * kScratchWords, "scratch size");
+        static_assert(sizeof(ColdBlock) <= sizeof(unsigned long long) * (kScratchWords - kScratchColdWord), "cold block fits");
+        void* p = nullptr;
+        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = static_cast<unsigned long long*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+// Launches the tracer for photon IDs [pid_begin, pid_begin + count). `cursor` / `cold`: the device words the pool
+// kernel takes its photon-ID cursors and cold block from -- the context's own allocation (rt_trace) or the static
+// scratch (rt_trace_noalloc, which must not allocate: it refuses instead of building majorants).
+int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count, bool noalloc)
+{
+    const char* const who = noalloc ? "rt_trace_noalloc" : "rt_trace";
     if (!c) return fail(RT_ERR_ARG, "%s: null context", who);
     if (!c->have_optics || !c->have_scene)
         return fail(RT_ERR_STATE, "%s: call rt_upload_optics and rt_set_scene first", who);
@@ -1730,6 +1766,16 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     if (c->pool > 0 && count > 0 && pid_begin + count > (1ull << 40))
         return fail(RT_ERR_ARG, "%s: the pool kernel packs photon ids into 40 bits (ids up to 2^40; option pool = 0 "
                                 "carries 64-bit ids)", who);
+    if (noalloc)
+    {
+        if (c->pool == 0)
+            return fail(RT_ERR_ARG, "rt_trace_noalloc: needs the pool kernel (option pool > 0); the lane-resident "
+                                    "kernel has no scratch to place");
+        if (c->maj_dirty)
+            return fail(RT_ERR_STATE, "rt_trace_noalloc: the majorant tables are not built (they are allocated by "
+                                      "rt_prepare / rt_get_slabs / rt_trace): call rt_prepare after the last "
+                                      "rt_upload_optics or option change");
+    }
     RT_HIP(hipSetDevice(c->device));
     if (count == 0) { c->timed = false; return RT_OK; }
     if (c->maj_dirty)
@@ -1751,7 +1797,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
     }
     const bool gridded = sl.gslab >= 0;
 
-    RT_HIP(hipEventRecord(c->ev_start, c->stream));
+    if (!noalloc) RT_HIP(hipEventRecord(c->ev_start, c->stream));
     if (c->pool > 0)
     {
         // pool kernel: one wave per workgroup; LDS bounds the resident waves (160 KiB per CU)
@@ -1768,6 +1814,14 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
 
         unsigned long long* cursor = c->d_events + kCursorWord;
         ColdBlock* d_cold = c->d_cold;
+        if (noalloc)
+        {
+            unsigned long long* sp = nullptr;
+            const int rc = scratch_of_device(c->device, &sp);
+            if (rc != RT_OK) return rc;
+            cursor = sp;
+            d_cold = reinterpret_cast<ColdBlock*>(sp + kScratchColdWord);
+        }
         ColdBlock cb;
         memset(&cb, 0, sizeof(cb));
         cb.pid_begin = pid_begin; cb.total = count;
@@ -1882,8 +1936,13 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
         }
     }
     RT_HIP(hipGetLastError());
-    RT_HIP(hipEventRecord(c->ev_stop, c->stream));
-    c->timed = true;
+    if (!noalloc)
+    {
+        RT_HIP(hipEventRecord(c->ev_stop, c->stream));
+        c->timed = true;
+    }
+    else
+        c->timed = false;
     return RT_OK;
 }
 } // namespace
@@ -1939,6 +1998,12 @@ int rt_create(int device_id, int itot, int jtot, int ktot, float dx, float dy, f
         return fail(RT_ERR_HIP, "rt_create: allocation failed: %s", hipGetErrorString(e));
     }
     c->owns_tallies = true;
+    {
+        // set-up of the static scratch of rt_trace_noalloc: its address on this device, once per device
+        unsigned long long* sp = nullptr;
+        const int rc = scratch_of_device(device_id, &sp);
+        if (rc != RT_OK) { rt_destroy(c); return rc; }
+    }
     *out = c;
     return RT_OK;
 }
@@ -2076,7 +2141,12 @@ int rt_set_stream(rt_context* c, void* hip_stream)
 
 int rt_trace(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
 {
-    return trace_impl(c, seed, pid_begin, count);
+    return trace_impl(c, seed, pid_begin, count, false);
+}
+
+int rt_trace_noalloc(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count)
+{
+    return trace_impl(c, seed, pid_begin, count, true);
 }
 
 int rt_prepare(rt_context* c)

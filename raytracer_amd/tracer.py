@@ -58,6 +58,7 @@ def load_library():
         "rt_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
         "rt_set_stream": (C.c_int, [vp, vp]),
         "rt_trace": (C.c_int, [vp, u64, u64, u64]),
+        "rt_trace_noalloc": (C.c_int, [vp, u64, u64, u64]),
         "rt_prepare": (C.c_int, [vp]),
         "rt_synchronize": (C.c_int, [vp]),
         "rt_download_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
@@ -152,6 +153,10 @@ class PhotonTracer:
     # -- the hot path -----------------------------------------------------------------------
     def trace(self, seed, photon_id_begin, photon_count):
         _check(self.lib.rt_trace(self._h, int(seed), int(photon_id_begin), int(photon_count)))
+
+    def trace_noalloc(self, seed, photon_id_begin, photon_count):
+        """rt_trace for callers that cannot allocate (needs prepare() first; scratch in a static device array)."""
+        _check(self.lib.rt_trace_noalloc(self._h, int(seed), int(photon_id_begin), int(photon_count)))
 
     def prepare(self):
         """Build the majorant tables now, so that later trace() calls are pure asynchronous launches."""
