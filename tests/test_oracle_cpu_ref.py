@@ -62,3 +62,49 @@ def test_generalised_fields_equal_builtin_scene():
     assert O.balance(t) == 0
     p = int(t["surface_down_direct"].sum()) / int(t["toa_down"].sum())
     assert abs(p - 0.5878) < 0.005
+
+
+def test_large_fixtures_are_consistent_with_the_small_ones():
+    """tests/golden/make_golden_large.py: 2*10^8 photons of the compiled reference on its own scene (C1) must agree
+    with its 10^7-photon table; every fixture balances exactly and names the scene it was made with."""
+    from raytracer_amd import scenes
+    import hashlib
+    small = json.load(open(os.path.join(GOLD, "reference_1e7.json")))
+    g = np.load(os.path.join(GOLD, "reference_c1_2e8.npz"))
+    sums = dict(zip(O.TALLY_NAMES, (int(v) for v in g["sums"])))
+    n, ns = sums["toa_down"], small["sums"]["toa_down"]
+    assert n >= 200_000_000
+    for name in O.TALLY_NAMES[1:]:
+        p, q = sums[name] / n, small["sums"][name] / ns
+        assert abs(p - q) < 4 * np.sqrt(q * (1 - q) * (1 / n + 1 / ns)), name
+    lev = (g["level_direct"] + g["level_diffuse"]).astype(np.float64)
+    levs = np.array(small["atmos_level_sums"], dtype=np.float64)
+    z = (lev / n - levs / ns) / np.sqrt(levs / ns * (1 / n + 1 / ns))
+    assert np.max(np.abs(z)) < 5 and 0.6 < np.mean(z ** 2) < 1.5
+    for fname, factory, floor in (("reference_c1_2e8.npz", scenes.block_cloud, 200_000_000),
+                                  ("cpu_ref_c3_1e8.npz", scenes.cumulus_c3, 120_000_000)):
+        f = np.load(os.path.join(GOLD, fname))
+        s = [int(v) for v in f["sums"]]
+        assert s[0] >= floor and s[0] == s[2] + s[3] - s[4] + s[1] + s[5] + s[6]              # photon balance
+        assert int(f["level_direct"].sum()) == s[5] and int(f["level_diffuse"].sum()) == s[6]
+        for k, name in enumerate(O.TALLY_NAMES[:5]):
+            assert int(f["blocks_" + name].sum()) == s[k]
+        h = hashlib.md5()
+        for a in factory().fields():
+            h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        assert str(f["scene_md5"]) == h.hexdigest(), fname
+
+
+def test_restatement_agrees_with_its_large_fixture_on_c3():
+    """A fresh 1.5*10^6-photon run of oracle/cpu_ref.cpp on the cumulus scene against its own 1.2*10^8-photon
+    fixture (different thread count, hence different streams): fractions within 4 sigma."""
+    from raytracer_amd import scenes
+    f = np.load(os.path.join(GOLD, "cpu_ref_c3_1e8.npz"))
+    sums = [int(v) for v in f["sums"]]
+    t, _ = O.cpu_ref(O.scene_to_f64(scenes.cumulus_c3()), 1_500_000, nthreads=0)
+    n = int(t["toa_down"].sum())
+    for k, name in enumerate(O.TALLY_NAMES):
+        if k == 0:
+            continue
+        p, q = int(t[name].sum()) / n, sums[k] / sums[0]
+        assert abs(p - q) < 4 * np.sqrt(q * (1 - q) * (1 / n + 1 / sums[0])), name
