@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU sample")
+    ap.add_argument("--cpu-scenes", default="c1,c3",
+                    help="scenes timed on the CPU besides the benchmarked one (SURVEY.md section 8d asks for C1 and C3)")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--launch-log2k", type=int, default=5,
                     help="stratified launch: 2^k consecutive photon IDs per column (-1 = uniform launch positions); "
@@ -68,29 +70,63 @@ def parse():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each step's all-reduce before the next step starts")
+    ap.add_argument("--wire64", action="store_true",
+                    help="N > 1: all-reduce the 64-bit tallies as they are (default: 32-bit counts on the wire)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the collective code path even at world size 1")
     return ap.parse_args()
 
 
-def cpu_baseline(scene, seconds):
-    """Time oracle/cpu_ref.cpp (the checker, here only as the reported CPU baseline) on this host."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_sample(scene, seconds, threads):
+    """Time oracle/cpu_ref.cpp (the checker, here only as the reported CPU baseline) on this host: grow the
+    sample until it runs for about `seconds`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
     s64 = O.scene_to_f64(scene)
-    n, dt, t = 2_000_000, 0.0, None
-    for _ in range(4):                      # grow the sample until it runs for >= ~10 s
+    # (at least ~10 refills of the tracer's 65 536-photon batch: below that the tail of the last batch dominates)
+    n, dt, t = max(250_000 * threads, 800_000), 0.0, None
+    for _ in range(5):
         t0 = time.perf_counter()
-        t, _ = O.cpu_ref(s64, n, nthreads=cores)
+        t, _ = O.cpu_ref(s64, n, nthreads=threads)
         dt = time.perf_counter() - t0
-        if dt >= 0.8 * seconds:
+        if dt >= 0.7 * seconds:
             break
         n = int(min(n * max(1.5, 1.1 * seconds / max(dt, 1e-3)), 2e9))
     traced = int(t["toa_down"].sum())
-    return {"value": traced / dt, "unit": "photons/s", "cores": cores, "kind": "port",
-            "sample": f"{traced} photons of the same scene through oracle/cpu_ref.cpp "
-                      f"(double, xoroshiro128+, global majorant; bit-pinned to raytracer_3d.cpp) in {dt:.2f} s"}
+    return {"value": traced / dt, "unit": "photons/s", "cores": threads, "photons": traced, "seconds": dt}
+
+
+def cpu_baseline(scene, seconds, workload, extra_scenes):
+    """the bit-pinned restatement of raytracer_3d.cpp on all of this GPU's share of the host
+    cores and on one thread, CPU model named; the headline entry is the all-cores figure on the benchmarked scene."""
+    import raytracer_amd as rt
+    cores = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
+    full = cpu_sample(scene, seconds, cores)
+    one = cpu_sample(scene, seconds / 2, 1)
+    out = {"value": full["value"], "unit": "photons/s", "cores": cores, "kind": "port",
+           "sample": f"{full['photons']} photons of the same scene ({workload}) through oracle/cpu_ref.cpp "
+                     f"(double, xoroshiro128+, global majorant; bit-pinned to raytracer_3d.cpp) in {full['seconds']:.2f} s",
+           "cpu_model": cpu_model(),
+           "one_thread": {k: one[k] for k in ("value", "unit", "cores", "photons", "seconds")}}
+    others = {}
+    for wl in extra_scenes:
+        if wl == workload:
+            continue
+        sc = getattr(rt.scenes, WORKLOADS[wl][0])()
+        others[wl] = {"all_cores": cpu_sample(sc, seconds / 3, cores), "one_thread": cpu_sample(sc, seconds / 3, 1)}
+    if others:
+        out["other_scenes"] = others
+    return out
 
 
 def main():
@@ -140,49 +176,26 @@ def main():
     if launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
         launch_log2k = -1
     tr.set_option("launch_log2k", launch_log2k)
+    tr.prepare()            # majorant tables now: every trace below is a pure asynchronous launch
     stream = torch.cuda.current_stream()
-    tr.set_stream(stream.cuda_stream)
-    # uint64 bit patterns as int64 (sums wrap alike); two buffers when a collective follows the trace,
-    # so that the all-reduce of one step can run beside the trace of the next
-    overlap = use_dist and args.backend == "nccl" and not args.no_overlap
-    tallies = [torch.zeros(tr.nwords, dtype=torch.int64, device=dev) for _ in range(2 if overlap else 1)]
-    pending = [None] * len(tallies)
-    tr.bind_tally_tensor(tallies[0])
+    # The step is raytracer_amd.distributed.ShardedTracer.step -- the code the multi-rank tests check: zero a
+    # tally buffer, trace this rank's shard, start the ONE all-reduce (32-bit counts on the wire, two buffers so
+    # that it runs beside the next step's trace). ShardedTracer puts the tracer on torch's current stream.
+    sharded = rt.distributed.ShardedTracer(tr, dev, overlap=False if args.no_overlap else None,
+                                           wire32=not args.wire64, force_collective=args.force_dist)
+    overlap, use_dist = sharded.overlap, sharded.collective
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(idx, timed_slot=None):
-        b = idx % len(tallies)
-        tally = tallies[b]
-        if pending[b] is not None:          # the all-reduce that last used this buffer (two steps ago)
-            pending[b].wait()
-            pending[b] = None
-        if len(tallies) > 1:
-            tr.bind_tally_tensor(tally)
-        tr.reset()
-        begin = (idx * world + rank) * n_per_gpu
-        if timed_slot is not None:
-            starts[timed_slot].record(stream)
-        tr.trace(args.seed, begin, n_per_gpu)
-        if timed_slot is not None:
-            stops[timed_slot].record(stream)
-        if not use_dist:
-            return
-        if args.backend == "gloo":                      # rehearsal path: stage through the host
-            host = tally.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            tally.copy_(host)
-        elif overlap:                                   # ONE RCCL all-reduce, beside the next step's trace
-            pending[b] = dist.all_reduce(tally, op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            dist.all_reduce(tally, op=dist.ReduceOp.SUM)
+        # photon IDs of step idx: [idx * world * n_per_gpu, (idx + 1) * world * n_per_gpu), sharded over the ranks
+        return sharded.step(args.seed, world * n_per_gpu, idx * world * n_per_gpu,
+                            before_trace=(lambda: starts[timed_slot].record(stream)) if timed_slot is not None else None,
+                            after_trace=(lambda: stops[timed_slot].record(stream)) if timed_slot is not None else None)
 
     def fence():
-        for b, w in enumerate(pending):
-            if w is not None:
-                w.wait()
-                pending[b] = None
+        sharded.drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -192,8 +205,9 @@ def main():
         step(w)
     fence()
     t0 = time.perf_counter()
+    last = None
     for k in range(args.steps):
-        step(args.warmup + k, timed_slot=k)
+        last = step(args.warmup + k, timed_slot=k)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -206,7 +220,7 @@ def main():
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 
     # sanity on the last step's result (after the all-reduce every rank holds the node total)
-    words = tallies[(args.warmup + args.steps - 1) % len(tallies)].cpu().numpy()
+    words = sharded.result(last).cpu().numpy()
     t = rt.split_tally_words(words, scene.itot, scene.jtot, scene.ktot)
     launched = int(t["toa_down"].sum())
     balance = rt.photon_balance(t)
@@ -233,7 +247,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{desc}; 2^{log2n} photons per GPU per step; "
                                    f"grid {scene.itot}x{scene.jtot}x{scene.ktot}; zenith {scene.zenith_deg} deg, "
-                                   f"albedo {scene.albedo}; step = reset + trace" + ((" + RCCL all-reduce of tallies" if args.backend == "nccl" else " + gloo all-reduce staged through the host (rehearsal)") if use_dist else "")
+                                   f"albedo {scene.albedo}; step = reset + trace" + (((" + RCCL all-reduce of tallies" + (" (32-bit counts on the wire)" if sharded.wire32 else " (64-bit)")) if args.backend == "nccl" else " + gloo all-reduce staged through the host (rehearsal)") if use_dist else "")
                                    + (" (all-reduce of step k beside the trace of step k+1, double-buffered)" if overlap else ""),
                        "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}",
                        "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, "
@@ -254,6 +268,10 @@ def main():
                     p = json.load(fh)
                 if p.get("photons_per_launch") == n_per_gpu and p.get("launch_log2k", -1) == launch_log2k:
                     out["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+                    # counters cannot be read inside a plain run: these figures are REPLAYED from the committed
+                    # rocprofv3 PMC passes of this same command, not measured by this process
+                    out["roofline"]["traffic_source"] = out["counters_source"] = \
+                        f"profiles/pmc_{args.workload}.json (rocprofv3 --pmc passes of this command, kernel {p.get('kernel_avg_ns', 0) / 1e6:.2f} ms there; replayed, not measured in this run)"
                     # the same profile's counters priced against the measured gather and VALU ceilings
                     kt = avg_kernel_ms * 1e-3
                     if p.get("fabric_reads_per_photon") is not None:
@@ -275,7 +293,8 @@ def main():
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds, args.workload,
+                                               [w for w in args.cpu_scenes.split(",") if w in WORKLOADS])
     tr.close()
     if use_dist:
         dist.barrier()

@@ -32,18 +32,23 @@ struct Config
     float dx, dy, dz;
     float albedo = 0.2f;                      // raytracer_3d.cu:24
     std::vector<double> zenith_deg{50.};      // raytracer_3d.cu:25 (a list = resident-grid sweep)
-    double azimuth_deg = 20.;                 // raytracer_3d.cu:26
+    std::vector<double> azimuth_deg{20.};     // raytracer_3d.cu:26 (likewise; every pair of the two lists is run)
     uint64_t seed = 0;
     int ngpus = 1;
     std::string indir = ".", outdir = ".";
     int exponent = -1;
     bool fixed_dot = false;
-    // --launch=uniform (default) | auto | K: stratified launch, 2^K consecutive photon IDs per column
-    // (the library's "launch_log2k"; stands in for the reference's scrambled-Sobol launch positions).
-    // It samples the domain top evenly only over whole passes of ncol * 2^K photons per GPU; "auto"
-    // takes the largest K <= 5 for which the photon count allows that, else uniform.
+    // --launch=auto (default) | K | uniform: stratified launch, 2^K consecutive photon IDs per column
+    // (the library's "launch_log2k"; stands in for the reference's scrambled-Sobol launch positions,
+    // raytracer_kernels.cu:239-253, 331). It samples the domain top evenly only over whole passes of
+    // ncol * 2^K photons per GPU; "auto" takes the largest K <= 5 for which the photon count allows that,
+    // else uniform random positions.
     int launch_log2k = -1;
-    bool launch_auto = false;
+    bool launch_auto = true;
+    // --resume: the output directory already holds the seven tally files of an earlier run and its
+    // `checkpoint` file; this run adds photons [next_photon_id, next_photon_id + 2^n) to them (the restart the
+    // reference prepares for by copying its tally arrays to the device, raytracer_3d.cu:89, 98-104)
+    bool resume = false;
     bool input_f64 = false;                   // sidecar says the data files hold float64
 };
 
@@ -106,7 +111,7 @@ inline bool read_sidecar(const std::string& dir, Config& c)
             else if (key == "dz") c.dz = std::stof(val);
             else if (key == "albedo") c.albedo = std::stof(val);
             else if (key == "zenith_deg") c.zenith_deg = {std::stod(val)};
-            else if (key == "azimuth_deg") c.azimuth_deg = std::stod(val);
+            else if (key == "azimuth_deg") c.azimuth_deg = {std::stod(val)};
             else if (key == "dtype")
             {
                 if (val == "float64") c.input_f64 = true;
@@ -146,7 +151,15 @@ inline void parse_args(int argc, char** argv, Config& c)
             else if (key == "dy") c.dy = std::stof(val);
             else if (key == "dz") c.dz = std::stof(val);
             else if (key == "albedo") c.albedo = std::stof(val);
-            else if (key == "azimuth") c.azimuth_deg = std::stod(val);
+            else if (key == "azimuth")
+            {
+                c.azimuth_deg.clear();
+                std::stringstream ss(val);
+                std::string item;
+                while (std::getline(ss, item, ',')) c.azimuth_deg.push_back(std::stod(item));
+                if (c.azimuth_deg.empty()) die("--azimuth needs at least one angle");
+            }
+            else if (key == "resume") c.resume = (val != "0");
             else if (key == "seed") c.seed = std::stoull(val);
             else if (key == "ngpus") c.ngpus = std::stoi(val);
             else if (key == "indir") c.indir = val;
@@ -223,6 +236,73 @@ inline void load_binary(const std::string& dir, const std::string& name, float* 
 static const char* const kTallyNames[RT_N_TALLIES] = {
     "toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up", "atmos_direct", "atmos_diffuse"};
 
+// `checkpoint` beside the seven tally files: what a later --resume needs to continue the same photon sequence
+// (`key = value` lines). Every run writes it after its tallies.
+struct Checkpoint
+{
+    uint64_t seed = 0, next_photon_id = 0;
+    int itot = 0, jtot = 0, ktot = 0, launch_log2k = -1;
+    double zenith_deg = 0., azimuth_deg = 0.;
+    float albedo = 0.f;
+    bool fixed_dot = false;
+};
+
+inline void write_checkpoint(const std::string& dir, const Checkpoint& k)
+{
+    std::ofstream f(dir + "/checkpoint", std::ios::out | std::ios::trunc);
+    if (!f) throw std::runtime_error("Cannot write file \"checkpoint\"");
+    f << "# state of the tally files in this directory; continue with --resume\n"
+      << "seed = " << k.seed << "\nnext_photon_id = " << k.next_photon_id << "\n"
+      << "itot = " << k.itot << "\njtot = " << k.jtot << "\nktot = " << k.ktot << "\n"
+      << "launch_log2k = " << k.launch_log2k << "\n"
+      << std::setprecision(17) << "zenith_deg = " << k.zenith_deg << "\nazimuth_deg = " << k.azimuth_deg << "\n"
+      << std::setprecision(9) << "albedo = " << k.albedo << "\nfixed_dot = " << (k.fixed_dot ? 1 : 0) << "\n";
+}
+
+inline Checkpoint read_checkpoint(const std::string& dir)
+{
+    std::ifstream f(dir + "/checkpoint");
+    if (!f) die("--resume: cannot read file \"" + dir + "/checkpoint\" (written by an earlier run into the same --outdir)");
+    Checkpoint k;
+    std::string line;
+    while (std::getline(f, line))
+    {
+        line = trimmed(line.substr(0, line.find('#')));
+        if (line.empty()) continue;
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) die("checkpoint: expected `key = value`");
+        const std::string key = trimmed(line.substr(0, eq)), val = trimmed(line.substr(eq + 1));
+        try
+        {
+            if (key == "seed") k.seed = std::stoull(val);
+            else if (key == "next_photon_id") k.next_photon_id = std::stoull(val);
+            else if (key == "itot") k.itot = std::stoi(val);
+            else if (key == "jtot") k.jtot = std::stoi(val);
+            else if (key == "ktot") k.ktot = std::stoi(val);
+            else if (key == "launch_log2k") k.launch_log2k = std::stoi(val);
+            else if (key == "zenith_deg") k.zenith_deg = std::stod(val);
+            else if (key == "azimuth_deg") k.azimuth_deg = std::stod(val);
+            else if (key == "albedo") k.albedo = std::stof(val);
+            else if (key == "fixed_dot") k.fixed_dot = std::stoi(val) != 0;
+            else die("checkpoint: unknown key " + key);
+        }
+        catch (const std::logic_error&)
+        {
+            die("checkpoint: cannot parse value \"" + val + "\"");
+        }
+    }
+    return k;
+}
+
+inline void load_tally(const std::string& dir, const std::string& name, uint64_t* ptr, size_t count)
+{
+    std::ifstream f(dir + "/" + name + ".bin", std::ios::in | std::ios::binary);
+    if (!f) throw std::runtime_error("Cannot read file \"" + name + ".bin\"");
+    f.read(reinterpret_cast<char*>(ptr), count * sizeof(uint64_t));
+    if (static_cast<size_t>(f.gcount()) != count * sizeof(uint64_t) || f.peek() != std::ifstream::traits_type::eof())
+        throw std::runtime_error("File \"" + name + ".bin\" does not hold the " + std::to_string(count) + " counts of this grid");
+}
+
 // The body of run_ray_tracer after the fields exist (raytracer_3d.cu:72-203).
 inline void run(const Config& c, const std::vector<float>& k_gas, const std::vector<float>& k_cloud,
                 const std::vector<float>& ssa, const std::vector<float>& asy)
@@ -245,6 +325,36 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     else if (launch_log2k >= 0 && n_photons % ((uint64_t)c.ngpus * (ncol << launch_log2k)) != 0)
         std::cerr << "Warning: --launch=" << launch_log2k << " covers the domain top evenly only for whole passes of "
                   << (ncol << launch_log2k) << " photons per GPU" << std::endl;
+
+    const bool sweep_z = c.zenith_deg.size() > 1, sweep_a = c.azimuth_deg.size() > 1;
+    struct Job { double zen, azi; std::string dir; Checkpoint from; };
+    std::vector<Job> jobs;
+    for (const double zen : c.zenith_deg)
+        for (const double azi : c.azimuth_deg)
+        {
+            std::ostringstream d;
+            d << c.outdir;
+            if (sweep_z) d << "/zenith_" << std::setw(2) << std::setfill('0') << (int)std::lround(zen);
+            if (sweep_a) d << (sweep_z ? "_" : "/") << "azimuth_" << std::setw(3) << std::setfill('0') << (int)std::lround(azi);
+            Job job{zen, azi, d.str(), Checkpoint()};
+            if (c.resume)
+            {
+                // the earlier run's state: it fixes the photon sequence this run continues
+                job.from = read_checkpoint(job.dir);
+                const Checkpoint& k = job.from;
+                if (k.itot != c.itot || k.jtot != c.jtot || k.ktot != c.ktot) die("--resume: " + job.dir + " holds another grid");
+                if (k.seed != c.seed || k.zenith_deg != zen || k.azimuth_deg != azi || k.albedo != c.albedo || k.fixed_dot != c.fixed_dot)
+                    die("--resume: " + job.dir + "/checkpoint was written with another seed, sun position, albedo or physics option");
+                if (!c.launch_auto && k.launch_log2k != launch_log2k)
+                    die("--resume: " + job.dir + " was launched with --launch=" + std::to_string(k.launch_log2k));
+            }
+            jobs.push_back(job);
+        }
+    // a resumed run keeps the launch order of the run it continues (the passes over the columns go on)
+    if (c.resume) launch_log2k = jobs[0].from.launch_log2k;
+    for (const Job& job : jobs)
+        if (c.resume && job.from.launch_log2k != launch_log2k) die("--resume: the directories of this sweep disagree on the launch order");
+
     std::vector<rt_context*> ctx(c.ngpus, nullptr);
     auto t0 = std::chrono::high_resolution_clock::now();
     for (int g = 0; g < c.ngpus; ++g)
@@ -253,6 +363,8 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
         check(rt_upload_optics(ctx[g], k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
         check(rt_set_option(ctx[g], "fixed_dot", c.fixed_dot), "rt_set_option");
         check(rt_set_option(ctx[g], "launch_log2k", launch_log2k), "rt_set_option");
+        // majorant tables on every GPU now: the launches inside the timed region below are asynchronous
+        check(rt_prepare(ctx[g]), "rt_prepare");
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     rt_slab_info slabs;
@@ -261,57 +373,63 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
               << std::chrono::duration<double>(t1 - t0).count() << " (s)" << std::endl;
     std::cout << slabs.cloud_min << " - " << slabs.cloud_max << std::endl;      // raytracer_3d.cu:130
 
-    std::vector<std::vector<uint64_t>> host(RT_N_TALLIES), part(RT_N_TALLIES);
+    std::vector<std::vector<uint64_t>> host(RT_N_TALLIES);
+    uint64_t* ptrs[RT_N_TALLIES];
     for (int t = 0; t < RT_N_TALLIES; ++t)
     {
         host[t].resize(t < RT_ATMOS_DIRECT ? ncol : ncell);
-        part[t].resize(host[t].size());
+        ptrs[t] = host[t].data();
     }
 
-    for (size_t run_idx = 0; run_idx < c.zenith_deg.size(); ++run_idx)
+    for (const Job& job : jobs)
     {
-        const float zen = static_cast<float>(c.zenith_deg[run_idx] * (M_PI / 180.));   // raytracer_3d.cu:25
-        const float azi = static_cast<float>(c.azimuth_deg * (M_PI / 180.));
+        const float zen = static_cast<float>(job.zen * (M_PI / 180.));   // raytracer_3d.cu:25
+        const float azi = static_cast<float>(job.azi * (M_PI / 180.));   // raytracer_3d.cu:26
+        uint64_t first_id = 0;
         for (int g = 0; g < c.ngpus; ++g)
         {
             check(rt_set_scene(ctx[g], zen, azi, c.albedo), "rt_set_scene");
             check(rt_reset_tallies(ctx[g]), "rt_reset_tallies");
         }
+        if (c.resume)
+        {
+            // the counts so far go to GPU 0 (raytracer_3d.cu:98-104 copies its host arrays up for this); the sum
+            // over the GPUs below carries them into the total
+            first_id = job.from.next_photon_id;
+            for (int t = 0; t < RT_N_TALLIES; ++t) load_tally(job.dir, kTallyNames[t], host[t].data(), host[t].size());
+            check(rt_upload_tallies(ctx[0], ptrs), "rt_upload_tallies");
+            std::cout << "Resuming " << job.dir << " at photon " << first_id << std::endl;
+        }
         auto s0 = std::chrono::high_resolution_clock::now();
-        // photon IDs [0, n) split into contiguous shards, one per GPU; launches are asynchronous
+        // photon IDs [first, first + n) split into contiguous shards, one per GPU; launches are asynchronous
         const uint64_t base = n_photons / c.ngpus, rem = n_photons % c.ngpus;
-        uint64_t begin = 0;
+        uint64_t begin = first_id;
         for (int g = 0; g < c.ngpus; ++g)
         {
             const uint64_t cnt = base + ((uint64_t)g < rem ? 1 : 0);
             check(rt_trace(ctx[g], c.seed, begin, cnt), "rt_trace");
             begin += cnt;
         }
+        // the path's one exchange step: every GPU ends with the node total (RCCL over xGMI inside the library)
+        if (c.ngpus > 1) check(rt_allreduce(ctx.data(), c.ngpus), "rt_allreduce");
         for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
         auto s1 = std::chrono::high_resolution_clock::now();
         const double dur = std::chrono::duration<double>(s1 - s0).count();
         std::cout << "Duration: " << std::setprecision(5) << dur << " (s)" << std::endl;  // raytracer_3d.cu:169
         std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons / dur << std::endl;
 
-        for (int g = 0; g < c.ngpus; ++g)
+        check(rt_download_tallies(ctx[0], ptrs), "rt_download_tallies");
+        if (sweep_z || sweep_a)
         {
-            uint64_t* ptrs[RT_N_TALLIES];
-            for (int t = 0; t < RT_N_TALLIES; ++t) ptrs[t] = g == 0 ? host[t].data() : part[t].data();
-            check(rt_download_tallies(ctx[g], ptrs), "rt_download_tallies");
-            if (g > 0)
-                for (int t = 0; t < RT_N_TALLIES; ++t)
-                    for (size_t i = 0; i < host[t].size(); ++i) host[t][i] += part[t][i];
+            mkdir(job.dir.c_str(), 0777);
+            std::cout << "Writing " << job.dir << std::endl;
         }
-        std::string dir = c.outdir;
-        if (c.zenith_deg.size() > 1)
-        {
-            std::ostringstream d;
-            d << c.outdir << "/zenith_" << std::setw(2) << std::setfill('0') << (int)std::lround(c.zenith_deg[run_idx]);
-            dir = d.str();
-            mkdir(dir.c_str(), 0777);
-            std::cout << "Writing " << dir << std::endl;
-        }
-        for (int t = 0; t < RT_N_TALLIES; ++t) save_binary(dir, kTallyNames[t], host[t].data(), host[t].size());
+        for (int t = 0; t < RT_N_TALLIES; ++t) save_binary(job.dir, kTallyNames[t], host[t].data(), host[t].size());
+        Checkpoint k;
+        k.seed = c.seed; k.next_photon_id = first_id + n_photons;
+        k.itot = c.itot; k.jtot = c.jtot; k.ktot = c.ktot; k.launch_log2k = launch_log2k;
+        k.zenith_deg = job.zen; k.azimuth_deg = job.azi; k.albedo = c.albedo; k.fixed_dot = c.fixed_dot;
+        write_checkpoint(job.dir, k);
     }
     for (int g = 0; g < c.ngpus; ++g) rt_destroy(ctx[g]);
 }

@@ -142,7 +142,8 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    stage into full waves; 0 = photon state stays in the lane's registers
  *                    (scheduling only: results do not change). "pool_waves_per_cu" caps residency.
  *   "blocks_per_cu"  workgroups of 256 lanes per compute unit of the persistent launch (default 6)
- *   "stats"          1: rt_trace also counts events (rt_get_events); 0 (default): it does not */
+ *   "stats"          1: rt_trace also counts events (rt_get_events); 0 (default): it does not
+ *   "wire32"         1 (default): rt_allreduce sums 32-bit counts when every count allows it; 0: always 64-bit */
 int rt_set_option(rt_context* ctx, const char* name, long long value);
 
 /* Launch on this HIP stream (a hipStream_t) from now on; NULL = the null stream. */
@@ -204,6 +205,26 @@ int rt_tally_device_buffer(rt_context* ctx, void** device_ptr, size_t* n_words);
  * order: launches already enqueued keep the buffer they were given, and the call does not wait for them (it
  * waits only when the buffer it replaces is the context's own, which it frees). */
 int rt_bind_tally_buffer(rt_context* ctx, void* device_ptr, size_t n_words);
+
+/* The path's one exchange step (the reference is single-GPU and has no counterpart): sums
+ * the tallies of n contexts -- one per GPU, same grid, all in this process -- so that every context holds the
+ * node total, with ONE RCCL all-reduce per GPU (ncclAllReduce, ncclSum) over xGMI inside one group call. RCCL is
+ * loaded at run time (librccl.so.1; a copy already mapped into the process, e.g. PyTorch's, is reused) and the
+ * communicators of a device set are created once and kept. Counts travel as 32-bit words (half the bytes: 1 GiB
+ * instead of 2 GiB per GPU on the 1024x1024x128 grid) whenever every count of every GPU is below 2^32 / n, which
+ * the narrowing kernel checks on the device; otherwise, or with option "wire32" = 0, as ncclUint64. Blocks until
+ * the sums are in place on every GPU. Works for n = 1 too (RCCL is still called). */
+int rt_allreduce(rt_context* const ctx[], int n);
+
+/* The two halves of the 32-bit exchange for hosts that run the collective themselves, one process per GPU
+ * (bench.py and raytracer_amd/distributed.py through torch.distributed = RCCL): rt_tallies_narrow writes the low
+ * words of the tally buffer (`tallies`, or the context's current buffer if NULL) to wire[0 .. n_words) and raises
+ * wire[n_words] to 1 if any count is at or above 2^32 / world_size (rounded down to a power of two); the host
+ * all-reduces the n_words + 1 uint32 words with a sum; rt_tallies_widen then stores the sums back as 64-bit counts
+ * unless wire[n_words] != 0 (some rank had a large count), in which case it leaves the tallies untouched and the
+ * host must all-reduce the 64-bit buffer instead. Both are asynchronous on the context's stream. */
+int rt_tallies_narrow(rt_context* ctx, const void* tallies, void* wire, int world_size);
+int rt_tallies_widen(rt_context* ctx, void* tallies, const void* wire);
 
 /* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
 int rt_get_slabs(rt_context* ctx, rt_slab_info* out);

@@ -27,6 +27,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1424,6 +1425,32 @@ __global__ void rt_add_u64_kernel(unsigned long long* __restrict__ dst, const un
         dst[i] += src[i];
 }
 
+// The two kernels either side of a 32-bit all-reduce of the tallies (halves the bytes on
+// xGMI). Narrow: wire[i] = low word of tallies[i]; any word at or above 2^guard_shift (whose sum over the ranks
+// could pass 2^32) raises the flag in wire[n]. Widen (after the sum, flag included): if no rank raised the flag
+// the sums replace the 64-bit tallies, otherwise those are left as they were for the caller's 64-bit fallback.
+__global__ void rt_narrow_kernel(const unsigned long long* __restrict__ tallies, uint32_t* __restrict__ wire, size_t n,
+                                 int guard_shift)
+{
+    uint32_t big = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const unsigned long long t = tallies[i];
+        big |= (uint32_t)((t >> guard_shift) != 0ull);
+        wire[i] = (uint32_t)t;
+    }
+    if (__ballot(big != 0u) != 0ull && (threadIdx.x & 63) == 0)
+        atomicOr(&wire[n], 1u);
+}
+
+__global__ void rt_widen_kernel(unsigned long long* __restrict__ tallies, const uint32_t* __restrict__ wire, size_t n)
+{
+    if (wire[n] != 0u)
+        return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        tallies[i] = (unsigned long long)wire[i];
+}
+
 __global__ void rt_selftest_philox_kernel(const uint32_t* ctr, size_t n, uint32_t k0, uint32_t k1, uint32_t* out)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1502,6 +1529,8 @@ struct rt_context
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
+    uint32_t* d_wire = nullptr;       // nwords + 1 words: 32-bit image of the tallies for rt_allreduce (allocated on first use)
+    bool wire32 = true;               // rt_allreduce sums 32-bit counts when every count allows it
     ColdBlock* d_cold = nullptr;
 
     bool have_optics = false, have_scene = false;
@@ -1747,6 +1776,138 @@ int scratch_of_device(int device, unsigned long long** out)
         g_scratch_ptr[device] = static_cast<unsigned long long*>(p);
     }
     *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+// ---- the path's one exchange step: a sum all-reduce of the tallies over the GPUs of the node (RCCL over xGMI) ----
+// RCCL is bound at run time (dlopen), so the library loads on hosts without it and, inside a process that already
+// carries an RCCL (PyTorch ships its own copy), uses that one instead of mapping a second.
+struct RcclApi
+{
+    void* handle = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclSum = 0, kNcclUint32 = 3, kNcclUint64 = 5;      // rccl.h: ncclSum, ncclUint32, ncclUint64
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+std::vector<std::pair<std::vector<int>, std::vector<void*>>> g_comm_sets;   // device list -> communicators (kept)
+
+int load_rccl()
+{
+    if (g_rccl.handle) return RT_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) return fail(RT_ERR_HIP, "rt_allreduce: cannot load RCCL (librccl.so.1): %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.CommInitAll || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString)
+        return fail(RT_ERR_HIP, "rt_allreduce: the RCCL library lacks one of the five entry points used");
+    g_rccl = a;
+    return RT_OK;
+}
+
+#define RT_NCCL(call)                                                                              \
+    do {                                                                                           \
+        const int r_ = (call);                                                                     \
+        if (r_ != 0)                                                                               \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// one communicator per GPU of the set, created once per distinct device list and kept for the process
+int comms_for(const std::vector<int>& devices, std::vector<void*>** out)
+{
+    for (auto& e : g_comm_sets)
+        if (e.first == devices) { *out = &e.second; return RT_OK; }
+    std::vector<void*> comms(devices.size(), nullptr);
+    RT_NCCL(g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data()));
+    g_comm_sets.emplace_back(devices, comms);
+    *out = &g_comm_sets.back().second;
+    return RT_OK;
+}
+
+int launch_narrow(rt_context* c, const unsigned long long* tallies, uint32_t* wire, int world)
+{
+    int guard_shift = 32;
+    for (int r = 1; r < world; r <<= 1) --guard_shift;       // R counts below 2^(32 - ceil(log2 R)) sum below 2^32
+    RT_HIP(hipMemsetAsync(wire + c->nwords, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(rt_narrow_kernel, dim3(2048), dim3(256), 0, c->stream, tallies, wire, c->nwords, guard_shift);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int allreduce_impl(rt_context* const ctx[], int n)
+{
+    if (!ctx || n < 1) return fail(RT_ERR_ARG, "rt_allreduce: needs at least one context");
+    std::vector<int> devices(n);
+    for (int g = 0; g < n; ++g)
+    {
+        if (!ctx[g]) return fail(RT_ERR_ARG, "rt_allreduce: context %d is null", g);
+        if (ctx[g]->nwords != ctx[0]->nwords) return fail(RT_ERR_ARG, "rt_allreduce: context %d has another grid", g);
+        devices[g] = ctx[g]->device;
+        for (int h = 0; h < g; ++h)
+            if (devices[h] == devices[g])
+                return fail(RT_ERR_ARG, "rt_allreduce: contexts %d and %d share GPU %d (one context per GPU)", h, g, devices[g]);
+    }
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int rc = load_rccl();
+    if (rc != RT_OK) return rc;
+    std::vector<void*>* comms = nullptr;
+    rc = comms_for(devices, &comms);
+    if (rc != RT_OK) return rc;
+    const size_t nwords = ctx[0]->nwords;
+    bool narrow = true;
+    for (int g = 0; g < n; ++g) narrow = narrow && ctx[g]->wire32;
+    if (narrow)
+    {
+        for (int g = 0; g < n; ++g)
+        {
+            rt_context* c = ctx[g];
+            RT_HIP(hipSetDevice(c->device));
+            if (!c->d_wire) RT_HIP(hipMalloc(&c->d_wire, sizeof(uint32_t) * (nwords + 1)));
+            rc = launch_narrow(c, c->d_tallies, c->d_wire, n);
+            if (rc != RT_OK) return rc;
+        }
+        RT_NCCL(g_rccl.GroupStart());
+        for (int g = 0; g < n; ++g)
+            RT_NCCL(g_rccl.AllReduce(ctx[g]->d_wire, ctx[g]->d_wire, nwords + 1, kNcclUint32, kNcclSum, (*comms)[g], ctx[g]->stream));
+        RT_NCCL(g_rccl.GroupEnd());
+        uint32_t flag = 0;
+        for (int g = 0; g < n; ++g)
+        {
+            rt_context* c = ctx[g];
+            RT_HIP(hipSetDevice(c->device));
+            hipLaunchKernelGGL(rt_widen_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_tallies, c->d_wire, nwords);
+            RT_HIP(hipGetLastError());
+        }
+        for (int g = 0; g < n; ++g)
+        {
+            rt_context* c = ctx[g];
+            RT_HIP(hipSetDevice(c->device));
+            RT_HIP(hipStreamSynchronize(c->stream));
+            if (g == 0) RT_HIP(hipMemcpy(&flag, c->d_wire + nwords, sizeof(flag), hipMemcpyDeviceToHost));
+        }
+        if (flag == 0) return RT_OK;
+        // some count was too large for 32 bits on the wire: the 64-bit tallies are untouched, sum those
+    }
+    RT_NCCL(g_rccl.GroupStart());
+    for (int g = 0; g < n; ++g)
+        RT_NCCL(g_rccl.AllReduce(ctx[g]->d_tallies, ctx[g]->d_tallies, nwords, kNcclUint64, kNcclSum, (*comms)[g], ctx[g]->stream));
+    RT_NCCL(g_rccl.GroupEnd());
+    for (int g = 0; g < n; ++g)
+    {
+        RT_HIP(hipSetDevice(ctx[g]->device));
+        RT_HIP(hipStreamSynchronize(ctx[g]->stream));
+    }
     return RT_OK;
 }
 
@@ -2019,6 +2180,7 @@ int rt_destroy(rt_context* c)
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_wire) (void)hipFree(c->d_wire);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -2071,6 +2233,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     if (!c || !name) return fail(RT_ERR_ARG, "rt_set_option: null argument");
     if (!strcmp(name, "fixed_dot")) c->fixed_dot = value != 0;
     else if (!strcmp(name, "stats")) c->stats = value != 0;
+    else if (!strcmp(name, "wire32")) c->wire32 = value != 0;
     else if (!strcmp(name, "planar")) c->planar = value != 0;
     else if (!strcmp(name, "blocks_per_cu"))
     {
@@ -2250,6 +2413,31 @@ int rt_bind_tally_buffer(rt_context* c, void* ptr, size_t n_words)
     }
     c->d_tallies = (unsigned long long*)ptr;
     c->owns_tallies = false;
+    return RT_OK;
+}
+
+int rt_allreduce(rt_context* const ctx[], int n)
+{
+    return allreduce_impl(ctx, n);
+}
+
+int rt_tallies_narrow(rt_context* c, const void* tallies, void* wire, int world_size)
+{
+    if (!c || !wire) return fail(RT_ERR_ARG, "rt_tallies_narrow: null argument");
+    if (world_size < 1 || world_size > 65536) return fail(RT_ERR_ARG, "rt_tallies_narrow: world size %d", world_size);
+    if (((uintptr_t)wire & 3u) != 0 || ((uintptr_t)tallies & 7u) != 0) return fail(RT_ERR_ARG, "rt_tallies_narrow: misaligned buffer");
+    RT_HIP(hipSetDevice(c->device));
+    return launch_narrow(c, tallies ? (const unsigned long long*)tallies : c->d_tallies, (uint32_t*)wire, world_size);
+}
+
+int rt_tallies_widen(rt_context* c, void* tallies, const void* wire)
+{
+    if (!c || !wire) return fail(RT_ERR_ARG, "rt_tallies_widen: null argument");
+    if (((uintptr_t)wire & 3u) != 0 || ((uintptr_t)tallies & 7u) != 0) return fail(RT_ERR_ARG, "rt_tallies_widen: misaligned buffer");
+    RT_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(rt_widen_kernel, dim3(2048), dim3(256), 0, c->stream,
+                       tallies ? (unsigned long long*)tallies : c->d_tallies, (const uint32_t*)wire, c->nwords);
+    RT_HIP(hipGetLastError());
     return RT_OK;
 }
 

@@ -6,7 +6,11 @@ rank r of R traces the contiguous ID range ``shard(total, r, R)`` against replic
 per-rank integer tallies are summed once: the result is bit-identical for every R.
 
 One process per GPU, ``torch.distributed`` with backend ``"nccl"`` (RCCL over xGMI) on the GPUs;
-``"gloo"`` on CPU tensors is what the CPU tests use to exercise the same code.
+``"gloo"`` is what the CPU tests and the one-GPU rehearsals use to exercise the same code.
+``ShardedTracer`` is the step ``bench.py`` times and the tests check: trace this rank's shard, then ONE
+all-reduce, double-buffered so that the all-reduce of job k runs beside the trace of job k+1, with the
+counts on the wire as 32-bit words whenever they fit (half the bytes over xGMI's point-to-point links).
+Several GPUs in ONE process (the C++ drivers' model) use ``rt_allreduce`` of the C ABI instead.
 """
 from __future__ import annotations
 
@@ -21,6 +25,13 @@ def shard(total: int, rank: int, world: int):
     return begin, base + (1 if rank < rem else 0)
 
 
+def _dist_state(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group), dist.get_backend(group)
+    return 0, 1, None
+
+
 def allreduce_tallies(tally_tensor, group=None):
     """Sum the concatenated tally buffer (int64 view of the uint64 counts; two's-complement sums
     wrap identically) over all ranks, in place. No-op when torch.distributed is not initialised
@@ -32,15 +43,134 @@ def allreduce_tallies(tally_tensor, group=None):
     return tally_tensor
 
 
+def _follow_torch_stream(tracer, tensor):
+    """torch's collectives are ordered against torch's CURRENT stream; the tracer launches on its own. Make them
+    the same stream, so that the all-reduce cannot read a buffer the tracer is still adding to."""
+    if getattr(tensor, "is_cuda", False) and hasattr(tracer, "set_stream"):
+        import torch
+        tracer.set_stream(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
 def trace_sharded(tracer, tally_tensor, seed: int, total_photons: int, first_photon_id: int = 0, group=None):
     """Trace this rank's shard of `total_photons` IDs starting at `first_photon_id` on `tracer`
-    (whose tallies are bound to `tally_tensor`), then all-reduce. Returns (begin, count)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-    else:
-        rank, world = 0, 1
+    (whose tallies are bound to `tally_tensor`), then all-reduce. The tracer is put on torch's current
+    stream first (see _follow_torch_stream). Returns (begin, count)."""
+    rank, world, _ = _dist_state(group)
     begin, count = shard(total_photons, rank, world)
+    _follow_torch_stream(tracer, tally_tensor)
     tracer.trace(seed, first_photon_id + begin, count)
     allreduce_tallies(tally_tensor, group)
     return first_photon_id + begin, count
+
+
+# resident waves per CU of the pool kernel while a collective may be pending: leaves 160 - 22 * 6.1 = 26 KiB of
+# every CU's LDS free, more than RCCL's gfx950 kernels ask for (21 184 B), so the all-reduce kernel is placed at once
+# instead of waiting for a whole trace (profiles/r1_overlap_probe.txt); costs the trace about 4 %
+POOL_WAVES_BESIDE_A_COLLECTIVE = 22
+
+
+class ShardedTracer:
+    """One rank's side of a multi-GPU job stream. `tracer` is a PhotonTracer (or anything with its
+    nwords / bind_tally_tensor / reset / trace / narrow_tallies / widen_tallies); `device` is where the tally
+    buffers live (the tracer's GPU, or "cpu" for a CPU stand-in).
+
+    step(seed, total, first_id) zeroes a tally buffer, traces this rank's shard of the job into it and starts the
+    job's ONE all-reduce; result(handle) returns the buffer holding the node total. With `overlap` (default for
+    nccl at world size > 1) two buffers alternate and the all-reduce is asynchronous: it runs beside the next
+    step's trace, and a step waits only for the all-reduce that used its buffer two steps earlier. With `wire32`
+    the counts cross the wire as 32-bit words (narrow -> all-reduce -> widen); if any rank holds a count too large
+    for that (the narrowing kernel checks on the device, the flag is summed with the data) result() repeats the
+    exchange on the 64-bit buffer, which the widening kernel then has left untouched."""
+
+    def __init__(self, tracer, device, group=None, overlap=None, wire32=True, force_collective=False,
+                 reserve_lds=True):
+        import torch
+        self.torch = torch
+        self.tracer, self.group = tracer, group
+        self.device = torch.device(device)
+        self.rank, self.world, self.backend = _dist_state(group)
+        self.collective = self.world > 1 or (force_collective and self.backend is not None)
+        # gloo cannot reduce device memory: stage through the host (rehearsals and tests on one GPU)
+        self.stage_through_host = self.collective and self.backend == "gloo" and self.device.type == "cuda"
+        if overlap is None:
+            overlap = self.collective and self.backend == "nccl"
+        self.overlap = bool(overlap) and self.collective and not self.stage_through_host
+        self.wire32 = bool(wire32) and self.collective and not self.stage_through_host
+        nbuf = 2 if self.overlap else 1
+        n = tracer.nwords
+        self.tallies = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(nbuf)]
+        self.wire = [torch.zeros(n + 1, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if self.wire32 else None
+        self.pending = [None] * nbuf
+        self.exchanged = [False] * nbuf
+        self.steps = 0
+        _follow_torch_stream(tracer, self.tallies[0])
+        if self.overlap and reserve_lds and hasattr(tracer, "set_option"):
+            tracer.set_option("pool_waves_per_cu", POOL_WAVES_BESIDE_A_COLLECTIVE)
+        tracer.bind_tally_tensor(self.tallies[0])
+
+    def span(self, total_photons, first_photon_id=0):
+        begin, count = shard(total_photons, self.rank, self.world)
+        return first_photon_id + begin, count
+
+    def step(self, seed, total_photons, first_photon_id=0, before_trace=None, after_trace=None):
+        """One job: returns the handle of its buffer (valid until the step after next reuses it)."""
+        import torch.distributed as dist
+        b = self.steps % len(self.tallies)
+        self.steps += 1
+        self._finish(b)
+        tally = self.tallies[b]
+        if len(self.tallies) > 1:
+            self.tracer.bind_tally_tensor(tally)
+        self.tracer.reset()
+        begin, count = self.span(total_photons, first_photon_id)
+        if before_trace is not None:
+            before_trace()
+        self.tracer.trace(seed, begin, count)
+        if after_trace is not None:
+            after_trace()
+        self.exchanged[b] = False
+        if not self.collective:
+            return b
+        if self.stage_through_host:
+            host = tally.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            tally.copy_(host)
+            self.exchanged[b] = True
+            return b
+        buf = tally
+        if self.wire32:
+            buf = self.wire[b]
+            self.tracer.narrow_tallies(buf, self.world, tally)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=self.overlap)
+        if self.overlap:
+            self.pending[b] = work
+        else:
+            self._after_exchange(b)
+        return b
+
+    def _after_exchange(self, b):
+        if self.wire32:
+            self.tracer.widen_tallies(self.wire[b], self.tallies[b])
+        self.exchanged[b] = True
+
+    def _finish(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()          # torch's current stream waits for the collective; the host does not
+            self.pending[b] = None
+            self._after_exchange(b)
+
+    def drain(self):
+        """Every started all-reduce is complete (in stream order) when this returns."""
+        for b in range(len(self.tallies)):
+            self._finish(b)
+
+    def result(self, handle):
+        """The buffer of step `handle` with the node total in it (synchronises this rank's stream)."""
+        import torch.distributed as dist
+        self._finish(handle)
+        tally = self.tallies[handle]
+        if self.wire32 and self.exchanged[handle] and int(self.wire[handle][-1].item()) != 0:
+            # a count too large for 32 bits somewhere: every rank sees the same flag sum and repeats in 64 bits
+            dist.all_reduce(tally, op=dist.ReduceOp.SUM, group=self.group)
+            self.wire[handle][-1] = 0       # done: a second result() must not add again
+        return tally

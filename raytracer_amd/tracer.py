@@ -66,6 +66,9 @@ def load_library():
         "rt_reset_tallies": (C.c_int, [vp]),
         "rt_tally_device_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
+        "rt_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "rt_tallies_narrow": (C.c_int, [vp, vp, vp, C.c_int]),
+        "rt_tallies_widen": (C.c_int, [vp, vp, vp]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
         "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
         "rt_get_region_levels": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_size_t]),
@@ -157,6 +160,19 @@ class PhotonTracer:
     def trace_noalloc(self, seed, photon_id_begin, photon_count):
         """rt_trace for callers that cannot allocate (needs prepare() first; scratch in a static device array)."""
         _check(self.lib.rt_trace_noalloc(self._h, int(seed), int(photon_id_begin), int(photon_count)))
+
+    def narrow_tallies(self, wire_tensor, world_size, tally_tensor=None):
+        """Low words of the tallies (of `tally_tensor`, default: the bound buffer) into an int32 device tensor of
+        nwords + 1 elements; the last one becomes 1 if a count is too large for a 32-bit sum over world_size ranks."""
+        if wire_tensor.numel() != self.nwords + 1 or wire_tensor.element_size() != 4 or not wire_tensor.is_contiguous():
+            raise RtError(f"wire tensor must be contiguous, 4-byte, {self.nwords + 1} elements")
+        src = C.c_void_p(tally_tensor.data_ptr()) if tally_tensor is not None else None
+        _check(self.lib.rt_tallies_narrow(self._h, src, C.c_void_p(wire_tensor.data_ptr()), int(world_size)))
+
+    def widen_tallies(self, wire_tensor, tally_tensor=None):
+        """The summed 32-bit words back into the 64-bit tallies, unless the flag word says a rank refused."""
+        dst = C.c_void_p(tally_tensor.data_ptr()) if tally_tensor is not None else None
+        _check(self.lib.rt_tallies_widen(self._h, dst, C.c_void_p(wire_tensor.data_ptr())))
 
     def prepare(self):
         """Build the majorant tables now, so that later trace() calls are pure asynchronous launches."""
@@ -250,6 +266,14 @@ class PhotonTracer:
             self.close()
         except Exception:
             pass
+
+
+def allreduce(tracers):
+    """rt_allreduce over several PhotonTracer objects of ONE process (one per GPU): every tracer ends up holding
+    the summed tallies (RCCL inside the library)."""
+    lib = load_library()
+    arr = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
+    _check(lib.rt_allreduce(arr, len(tracers)))
 
 
 def split_tally_words(words, itot, jtot, ktot):

@@ -70,6 +70,74 @@ def test_two_ranks_reproduce_single_process_tallies(tmp_path):
     assert spans[0][0] == 5 and spans[0][0] + spans[0][1] == spans[1][0] and spans[0][1] + spans[1][1] == total
 
 
+class _CpuTracer:
+    """Stand-in with PhotonTracer's interface as ShardedTracer uses it, on CPU tensors: the oracle traces, and
+    narrow / widen restate rt_narrow_kernel / rt_widen_kernel (the GPU tests check the kernels themselves)."""
+
+    def __init__(self, scene, extra=0):
+        self.scene, self.nwords, self.tensor, self.extra = scene, 5 * scene.ncol + 2 * scene.ncell, None, extra
+
+    def bind_tally_tensor(self, t):
+        self.tensor = t
+
+    def reset(self):
+        self.tensor.zero_()
+
+    def trace(self, seed, begin, count):
+        t, _ = O.photon_oracle(self.scene, seed, begin, count, nthreads=1)
+        words = np.concatenate([t[n].ravel() for n in O.TALLY_NAMES]).view(np.int64)
+        self.tensor += torch.from_numpy(words.copy())
+        self.tensor[3] += self.extra               # a count that may not fit 32 bits on the wire
+
+    def narrow_tallies(self, wire, world, tally=None):
+        t = tally if tally is not None else self.tensor
+        guard = 32 - int(np.ceil(np.log2(world))) if world > 1 else 32
+        wire[:-1] = torch.from_numpy((t.numpy() & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+        wire[-1] = int(bool(((t >> guard) != 0).any()))
+
+    def widen_tallies(self, wire, tally=None):
+        t = tally if tally is not None else self.tensor
+        if int(wire[-1]) == 0:
+            t.copy_(torch.from_numpy(wire[:-1].numpy().view(np.uint32).astype(np.int64)))
+
+
+def _sharded_worker(rank, world, port, out_dir, overlap, wire32, extra):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.tiny()
+    st = D.ShardedTracer(_CpuTracer(sc, extra if rank == 1 else 0), "cpu", overlap=overlap, wire32=wire32)
+    assert st.collective and st.overlap == overlap and st.wire32 == wire32 and len(st.tallies) == (2 if overlap else 1)
+    jobs = [(31, 3001, 7), (32, 2000, 100000), (33, 4099, 0)]          # (seed, photons, first id)
+    handles = []
+    for k, (seed, total, first) in enumerate(jobs):
+        handles.append(st.step(seed, total, first))
+        if k >= 1 or not overlap:            # a buffer is reused two steps later: read it before that
+            kk = k - 1 if overlap else k
+            np.save(os.path.join(out_dir, f"job{kk}_rank{rank}.npy"), st.result(handles[kk]).numpy().copy())
+    if overlap:
+        np.save(os.path.join(out_dir, f"job{len(jobs) - 1}_rank{rank}.npy"), st.result(handles[-1]).numpy().copy())
+    st.drain()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap,wire32,extra", [(False, False, 0), (True, True, 0), (False, True, 0),
+                                                  (True, True, 1 << 31), (True, False, 1 << 33)])
+def test_sharded_tracer_steps_reproduce_single_process_tallies(tmp_path, overlap, wire32, extra):
+    """ShardedTracer (the step bench.py times): three jobs over two ranks, with and without the double-buffered
+    asynchronous all-reduce, with 32-bit counts on the wire -- including a count of 2^31 on one rank, which the
+    narrowing step must flag so that the exchange is repeated in 64 bits."""
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path), overlap, wire32, extra), nprocs=world, join=True)
+    sc = scenes.tiny()
+    for k, (seed, total, first) in enumerate([(31, 3001, 7), (32, 2000, 100000), (33, 4099, 0)]):
+        whole, _ = O.photon_oracle(sc, seed, first, total, nthreads=0)
+        want = np.concatenate([whole[n].ravel() for n in O.TALLY_NAMES]).view(np.int64).copy()
+        want[3] += extra
+        r0, r1 = (np.load(tmp_path / f"job{k}_rank{r}.npy") for r in range(2))
+        assert np.array_equal(r0, r1) and np.array_equal(r0, want), (k, np.flatnonzero(r0 != want)[:5])
+
+
 def test_allreduce_is_noop_without_process_group():
     t = torch.arange(5, dtype=torch.int64)
     assert D.allreduce_tallies(t) is t and t.tolist() == [0, 1, 2, 3, 4]

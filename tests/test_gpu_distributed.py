@@ -1,0 +1,162 @@
+"""The multi-GPU path with the HIP kernel as the per-rank worker (the CPU tests use the oracle in its place):
+two ranks on the one GPU of the test box over gloo, the RCCL calls at world size 1, the 32-bit wire kernels, and
+rt_allreduce of the C ABI. Summed tallies must be bit-identical to one call."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+JOBS = [(31, 200_001, 7), (32, 1 << 17, 5_000_000_000), (33, 77_777, 0)]      # (seed, photons, first id)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _words(t):
+    return np.concatenate([t[n].ravel() for n in O.TALLY_NAMES]).view(np.int64)
+
+
+def _single_call(rt, scene, **opts):
+    out = []
+    tr = rt.PhotonTracer.from_scene(scene, **opts)
+    for seed, total, first in JOBS:
+        tr.reset(); tr.trace(seed, first, total); tr.synchronize()
+        out.append(_words(tr.tallies()).copy())
+    tr.close()
+    return out
+
+
+def _rank_worker(rank, world, port, out_dir, launch_log2k):
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    scene = rt.scenes.tiny()
+    tr = rt.PhotonTracer.from_scene(scene, device=0, launch_log2k=launch_log2k)
+    st = rt.distributed.ShardedTracer(tr, "cuda:0")
+    assert st.collective and st.stage_through_host and not st.overlap
+    for k, (seed, total, first) in enumerate(JOBS):
+        h = st.step(seed, total, first)
+        np.save(os.path.join(out_dir, f"job{k}_rank{rank}.npy"), st.result(h).cpu().numpy())
+    tr.synchronize()
+    tr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("launch_log2k", [-1, 2])
+def test_two_ranks_on_one_gpu_reproduce_a_single_call(tmp_path, launch_log2k):
+    """world size 2 over gloo, both ranks on cuda:0, each tracing its shard with the HIP kernel through
+    ShardedTracer (the step bench.py times): every rank ends with the tallies of one rt_trace call over the whole
+    range, bit for bit."""
+    import torch.multiprocessing as mp
+    import raytracer_amd as rt
+    world = 2
+    mp.spawn(_rank_worker, args=(world, _free_port(), str(tmp_path), launch_log2k), nprocs=world, join=True)
+    want = _single_call(rt, rt.scenes.tiny(), launch_log2k=launch_log2k)
+    for k in range(len(JOBS)):
+        r0, r1 = (np.load(tmp_path / f"job{k}_rank{r}.npy") for r in range(2))
+        assert np.array_equal(r0, r1) and np.array_equal(r0, want[k]), (k, np.flatnonzero(r0 != want[k])[:5])
+
+
+def test_rccl_world_size_one_overlapped_32bit_exchange(tmp_path):
+    """The exact path of bench.py --gpus N: backend nccl (RCCL), two tally buffers, asynchronous all-reduce of
+    32-bit counts (narrow kernel -> ncclAllReduce -> widen kernel), here at world size 1 in this process."""
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        scene = rt.scenes.tiny()
+        tr = rt.PhotonTracer.from_scene(scene, device=0)
+        st = rt.distributed.ShardedTracer(tr, "cuda:0", force_collective=True, overlap=True)
+        assert st.collective and st.overlap and st.wire32 and len(st.tallies) == 2
+        got, handles = [], []
+        for k, (seed, total, first) in enumerate(JOBS):
+            handles.append(st.step(seed, total, first))
+            if k >= 1:
+                got.append(st.result(handles[k - 1]).cpu().numpy().copy())
+        got.append(st.result(handles[-1]).cpu().numpy().copy())
+        tr.synchronize()
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+    want = _single_call(rt, rt.scenes.tiny())
+    for k in range(len(JOBS)):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_narrow_and_widen_kernels(tmp_path):
+    """rt_tallies_narrow / rt_tallies_widen either side of a 32-bit sum over two 'ranks' (two contexts on this GPU,
+    the sum done with torch): equal to the 64-bit sum; a count at or above 2^31 raises the flag and the widening
+    kernel then leaves the tallies alone."""
+    import torch
+    import raytracer_amd as rt
+    scene = rt.scenes.tiny()
+    trs = [rt.PhotonTracer.from_scene(scene, device=0) for _ in range(2)]
+    n = trs[0].nwords
+    tal = [torch.zeros(n, dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    wire = [torch.zeros(n + 1, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    for r, tr in enumerate(trs):
+        tr.set_stream(torch.cuda.current_stream().cuda_stream)
+        tr.bind_tally_tensor(tal[r])
+        tr.trace(5, r * 100_000, 100_000)
+    want = (tal[0] + tal[1]).cpu().numpy()
+    for r, tr in enumerate(trs):
+        tr.narrow_tallies(wire[r], 2)
+    total = wire[0] + wire[1]
+    assert int(total[-1].item()) == 0
+    for r, tr in enumerate(trs):
+        tr.widen_tallies(total)
+        assert np.array_equal(tal[r].cpu().numpy(), want)
+    # one large count on rank 1: flagged, tallies untouched by the widening
+    tal[1][7] = 1 << 31
+    before = tal[1].cpu().numpy().copy()
+    trs[1].narrow_tallies(wire[1], 2)
+    assert int(wire[1][-1].item()) == 1 and int(wire[1][7].item()) == -(1 << 31)
+    trs[1].widen_tallies(wire[1])
+    assert np.array_equal(tal[1].cpu().numpy(), before)
+    # at world size 1 the same count is fine (guard at 2^32)
+    trs[1].narrow_tallies(wire[1], 1)
+    assert int(wire[1][-1].item()) == 0
+    with pytest.raises(rt.RtError):
+        trs[0].narrow_tallies(torch.zeros(n, dtype=torch.int32, device="cuda:0"), 2)
+    for tr in trs:
+        tr.synchronize(); tr.close()
+
+
+@pytest.mark.parametrize("wire32", [1, 0])
+def test_rt_allreduce_of_the_c_abi(wire32):
+    """rt_allreduce (RCCL loaded at run time inside the library) on the one GPU there is: the sum over one context is
+    that context's tallies, through the 32-bit path, the 64-bit path, and the 32-bit path falling back to 64 bits
+    for a count of 2^32 + 5; two contexts on one GPU are refused."""
+    import raytracer_amd as rt
+    from raytracer_amd.tracer import allreduce
+    scene = rt.scenes.tiny()
+    tr = rt.PhotonTracer.from_scene(scene, wire32=wire32)
+    tr.trace(9, 0, 1 << 16); tr.synchronize()
+    want = tr.tallies()
+    allreduce([tr])
+    got = tr.tallies()
+    for name in O.TALLY_NAMES:
+        assert np.array_equal(got[name], want[name]), name
+    big = {n: np.zeros_like(v) for n, v in want.items()}
+    big["toa_up"][1, 2] = (1 << 32) + 5
+    tr.add_tallies(big)
+    allreduce([tr])
+    got = tr.tallies()
+    assert int(got["toa_up"][1, 2]) == int(want["toa_up"][1, 2]) + (1 << 32) + 5
+    other = rt.PhotonTracer.from_scene(scene)
+    with pytest.raises(rt.RtError, match="share GPU"):
+        allreduce([tr, other])
+    other.close(); tr.close()

@@ -33,10 +33,15 @@ def test_builtin_scene_driver(tmp_path):
     assert any(l.startswith("Duration: ") and l.endswith("(s)") for l in lines)
     sc = scenes.block_cloud()
     got = _read(tmp_path, sc)
-    want, _ = O.photon_oracle(sc, 0, 0, 1 << 18)
+    # the default launch is --launch=auto (the reference launches quasi-randomly, raytracer_kernels.cu:331):
+    # 2^18 photons are 16 = 2^4 whole passes over the 128 x 128 columns
+    want, _ = O.photon_oracle(sc, 0, 0, 1 << 18, launch_log2k=4)
     for n in TALLY_NAMES:
         assert np.array_equal(got[n], want[n]), n
     assert O.balance(got) == 0
+    assert int(np.abs(got["toa_down"].astype(np.int64) - 16).max()) <= 2          # even over the domain top
+    ck = dict(l.split(" = ") for l in open(tmp_path / "checkpoint").read().splitlines() if " = " in l)
+    assert ck["next_photon_id"] == str(1 << 18) and ck["launch_log2k"] == "4" and ck["seed"] == "0"
 
 
 def test_cli_contract(tmp_path):
@@ -66,6 +71,68 @@ def test_file_input_driver_and_zenith_sweep(tmp_path):
         got = _read(tmp_path / f"zenith_{zen:02d}", sc)
         for n in TALLY_NAMES:
             assert np.array_equal(got[n], want[n]), (zen, n)
+
+
+def test_resume_continues_the_photon_sequence(tmp_path):
+    """f2 (the restart raytracer_3d.cu:89, 98-104 prepares for): two runs of 2^17 photons, the second with --resume,
+    leave exactly the files of one run of 2^18 -- tallies and checkpoint -- for the built-in scene driver (stratified
+    launch, K fixed by the first run) and for the file driver (uniform launch, two GPUs' worth of shards)."""
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    sc = scenes.block_cloud()
+    r = subprocess.run([GPU, "18", "--launch=3", "--seed=11"], cwd=one, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([GPU, "17", "--launch=3", "--seed=11"], cwd=two, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    half = _read(two, sc)
+    assert int(half["toa_down"].sum()) == 1 << 17
+    r = subprocess.run([GPU, "17", "--seed=11", "--resume"], cwd=two, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"Resuming . at photon {1 << 17}" in r.stdout
+    a, b = _read(one, sc), _read(two, sc)
+    for n in TALLY_NAMES:
+        assert np.array_equal(a[n], b[n]), n
+    assert int(b["toa_down"].sum()) == 1 << 18 and O.balance(b) == 0
+    assert open(one / "checkpoint").read() == open(two / "checkpoint").read()
+    want, _ = O.photon_oracle(sc, 11, 0, 1 << 18, launch_log2k=3)
+    for n in TALLY_NAMES:
+        assert np.array_equal(b[n], want[n]), n
+    # what does not continue the same sequence is refused
+    for bad, msg in ((["--seed=12"], "another seed"), (["--seed=11", "--zenith=40"], "another seed, sun position"),
+                     (["--seed=11", "--launch=2"], "--launch=3"), (["--seed=11", "--itot=64"], "another grid")):
+        r = subprocess.run([GPU, "17", "--resume", *bad], cwd=two, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr)
+    r = subprocess.run([GPU, "17", "--resume"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "checkpoint" in r.stderr
+    # a third leg on the file driver, uniform launch, three legs of 2^15 == one call of 3 * 2^15 photon ids
+    tiny = scenes.tiny()
+    d = tmp_path / "io"
+    tiny.write(str(d))
+    for leg in range(3):
+        r = subprocess.run([IO, "15", "--seed=4"] + (["--resume"] if leg else []), cwd=d, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    want, _ = O.photon_oracle(tiny, 4, 0, 3 << 15)
+    got = _read(d, tiny)
+    for n in TALLY_NAMES:
+        assert np.array_equal(got[n], want[n]), n
+
+
+def test_zenith_and_azimuth_sweep(tmp_path):
+    """f2: --zenith=a,b --azimuth=c,d runs every pair with the grids resident, one directory each."""
+    sc = scenes.tiny()
+    sc.write(str(tmp_path))
+    r = subprocess.run([IO, "15", "--zenith=20,55", "--azimuth=0,135"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for zen in (20, 55):
+        for azi in (0, 135):
+            sc.zenith_deg, sc.azimuth_deg = float(zen), float(azi)
+            want, _ = O.photon_oracle(sc, 0, 0, 1 << 15)
+            got = _read(tmp_path / f"zenith_{zen:02d}_azimuth_{azi:03d}", sc)
+            for n in TALLY_NAMES:
+                assert np.array_equal(got[n], want[n]), (zen, azi, n)
+    r = subprocess.run([IO, "15", "--azimuth=90,270"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "azimuth_090" / "atmos_direct.bin").exists() and (tmp_path / "azimuth_270" / "checkpoint").exists()
 
 
 def test_stratified_launch_option_of_the_drivers(tmp_path):

@@ -128,3 +128,24 @@ def test_converter_follows_make_binary(tmp_path):
         convert.to_scene(nc, 1, 1, 1)
     with pytest.raises(RuntimeError, match="netCDF4|expected"):
         convert.load_fields(str(tmp_path / "missing.nc"))
+
+
+REF_PLOT = "/root/reference/python/plot_results_3d.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PLOT), reason="the reference tree is only present in the build container")
+def test_t7_reference_plot_script_runs_unmodified_on_our_files(tmp_path):
+    """the reference's own plot_results_3d.py, run as it is (headless, MPLBACKEND=Agg) in a
+    directory written by save_tallies for its 128^3 scene, reads the seven files and prints a photon balance of 0
+    (plot_results_3d.py:28-48). The tallies come from the CPU oracle here (the GPU drivers write the same files:
+    tests/test_gpu_drivers.py)."""
+    import subprocess
+    import sys
+    sc = scenes.block_cloud()
+    t, _ = O.photon_oracle(sc, 2, 0, 400_000)
+    save_tallies(t, str(tmp_path))
+    env = dict(os.environ, MPLBACKEND="Agg", MPLCONFIGDIR=str(tmp_path))
+    r = subprocess.run([sys.executable, REF_PLOT], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = dict(l.split(":", 1) for l in r.stdout.splitlines() if ":" in l)
+    assert int(lines["in"]) == 400_000 and int(lines["out"]) == 400_000 and int(lines["balance"]) == 0
