@@ -427,13 +427,13 @@ static inline void bump(uint64_t* p)
     ++*p;
 }
 
-/* Reciprocal of a direction component as the traversal keeps it: finite (+-FLT_MAX for a zero
- * component); its sign — not the component's — says which face of a region the photon heads for, so
- * (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component (a Lambert azimuth
+/* Reciprocal of a direction component as the traversal keeps it: finite (+-FLT_MAX for a component below
+ * 2^-100 in size, zero included); its sign — not the component's — says which face of a region the photon heads
+ * for, so (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component (a Lambert azimuth
  * draw of exactly 0 makes ux = +0). */
 static inline float dir_reciprocal(float u)
 {
-    return fminf(fmaxf(1.0f / u, -FLT_MAX), FLT_MAX);
+    return fabsf(u) >= 0x1p-100f ? 1.0f / u : copysignf(FLT_MAX, u);
 }
 
 /* distance along the ray (in units of the direction vector) to the face the photon heads for; a

@@ -169,20 +169,40 @@ __device__ __forceinline__ ColdPtr cold_of(const PoolArgs& a)
     return (ColdPtr)(uintptr_t)a.cold;
 }
 
+// The kernel's own argument block through the constant address space, made opaque once per stage: what a stage
+// reads of it are scalar loads issued inside that stage, not values held in scalar registers across the whole
+// loop (which is short of them: held there, they were spilled to VGPR lanes and read back with v_readlane, 16 per
+// event round). Used by the event stage for ITS arguments (cells, tallies, grid dimensions and reciprocal
+// spacings) and by the rare launch and slab stages for all of theirs; the traverse and new-direction stages keep
+// their arguments in registers (`a.`): loading those per round as well costs more in exposed scalar-load latency
+// than the spills did (measured on C4: all stages opaque 45.5 ms, none 44.3 ms, this split 43.6 ms).
+typedef const __attribute__((address_space(4))) PoolArgs* ArgPtr;
+__device__ __forceinline__ ArgPtr args_now()
+{
+    ArgPtr p = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+__device__ __forceinline__ ColdPtr cold_of_k(ArgPtr k)
+{
+    return (ColdPtr)(uintptr_t)k->cold;
+}
+
 __device__ __forceinline__ void tally_add(unsigned long long* p, unsigned long long v = 1ull)
 {
     // no-return 64-bit global atomic (write_photon_out, raytracer_kernels.cu:256-261)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Reciprocal of a direction component as the traversal stores it: finite (+-FLT_MAX for a zero
-// component), and its sign — not the component's — says which face of a region the photon heads for,
-// so that (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component.
+// Reciprocal of a direction component as the traversal stores it: finite (+-FLT_MAX for a component below
+// 2^-100 in size, zero included), and its sign — not the component's — says which face of a region the photon
+// heads for, so that (face - pos) * inv_u is never the 0 * inf or (-) * (+inf) of a zero component. Branch-free:
+// rt_rcp is 1.0f / u exactly on the range that takes it.
 __device__ __forceinline__ float dir_reciprocal(float u)
 {
-    if (__builtin_expect(__builtin_fabsf(u) >= 0x1p-100f, 1))
-        return rt::rt_rcp(u);            // == 1.0f / u there, and within +-2^100: nothing to clamp
-    return __builtin_fminf(__builtin_fmaxf(1.0f / u, -3.402823466e+38f), 3.402823466e+38f);
+    const float r = rt::rt_rcp(u);
+    return __builtin_fabsf(u) >= 0x1p-100f ? r : __builtin_copysignf(3.402823466e+38f, u);
 }
 
 // distance along the ray to the face the photon heads for; negative (past the face by rounding) -> 0
@@ -643,7 +663,7 @@ constexpr uint32_t kTickRounds = 1u << 17;
 // traverse steps a lane may take in one round of the traverse stage (a lane that crossed a face inside the grid
 // goes on into the next region at once instead of waiting for the next round)
 #ifndef RT_T_STEPS
-#define RT_T_STEPS 1
+#define RT_T_STEPS 2
 #endif
 constexpr int kPoolBlock = 64;
 
@@ -678,58 +698,50 @@ constexpr int kPoolBlock = 64;
                         bx0 = (ci >> L) << L; by0 = (cj >> L) << L; bz0 = (ck >> L) << L; \
                         bx1 = min(bx0 + (1 << L), a.nci); by1 = min(by0 + (1 << L), a.ncj); bz1 = min(bz0 + (1 << L), a.nck); \
                     } \
-                    const int cfx = (IX) > 0.0f ? bx1 : bx0, cfy = (IY) > 0.0f ? by1 : by0; \
+                    const bool px = (IX) > 0.0f, py = (IY) > 0.0f, up = (IZ) > 0.0f; \
+                    const int cfx = px ? bx1 : bx0, cfy = py ? by1 : by0, cfz = up ? bz1 : bz0; \
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx; \
                     const float fy = cfy == a.ncj ? a.ys : (float)cfy * a.hy; \
-                    const bool up = (IZ) > 0.0f; \
-                    const int cfz = up ? bz1 : bz0; \
                     const float fz = cfz == a.nck ? a.zc1 : fma_((float)cfz, a.hz, a.zc0); \
                     const float tx = face_distance(fx, x, (IX)); \
                     const float ty = face_distance(fy, y, (IY)); \
                     const float tz = face_distance(fz, z, (IZ)); \
-                    float t_exit = tx; int axis = 0; \
-                    if (ty < t_exit) { t_exit = ty; axis = 1; } \
-                    if (tz < t_exit) { t_exit = tz; axis = 2; } \
+                    const bool y_first = ty < tx; \
+                    const float txy = y_first ? ty : tx; \
+                    const bool z_first = tz < txy; \
+                    const float t_exit = z_first ? tz : txy; \
                     const float dn = tau * mm.y; \
                     const bool hit = t_exit <= dn; \
                     const float tt = hit ? t_exit : dn; \
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z); \
-                    if (HIER && L > 0) \
+                    if (HIER) \
                     { \
+                        /* inside a merged region the indices follow the position; for a region of one supervoxel */ \
+                        /* the clamp to [b0, b1 - 1] returns the index itself */ \
                         ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1); \
                         cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1); \
                         ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1); \
                     } \
-                    if (!hit) \
-                    { \
-                        ns = PS_COLLIDE; \
-                        tau = mm.y; \
-                    } \
-                    else \
-                    { \
-                        if (STATS) ++ev_trans; \
-                        tau = fma_(-tt, mm.x, tau); \
-                        tau = tau > 0.0f ? tau : 0.0f; \
-                        if (axis == 0) \
-                        { \
-                            x = fx; ci = (IX) > 0.0f ? bx1 : bx0 - 1; \
-                            if (ci == a.nci) { ci = 0; x = 0.0f; } \
-                            if (ci < 0) { ci = a.nci - 1; x = a.xs; } \
-                        } \
-                        else if (axis == 1) \
-                        { \
-                            y = fy; cj = (IY) > 0.0f ? by1 : by0 - 1; \
-                            if (cj == a.ncj) { cj = 0; y = 0.0f; } \
-                            if (cj < 0) { cj = a.ncj - 1; y = a.ys; } \
-                        } \
-                        else \
-                        { \
-                            z = fz; \
-                            const int nk = up ? bz1 : bz0 - 1; \
-                            if (nk >= 0 && nk < a.nck) ck = nk; \
-                            else { slab += up ? 1 : -1; ns = PS_SLAB; } \
-                        } \
-                    } \
+                    /* a face: carry tau on, step over the face (periodic in x and y); no face: 1/M rides in tau */ \
+                    const float tau_on = fma_(-tt, mm.x, tau); \
+                    tau = hit ? (tau_on > 0.0f ? tau_on : 0.0f) : mm.y; \
+                    const bool hit_x = hit && !y_first && !z_first, hit_y = hit && y_first && !z_first, hit_z = hit && z_first; \
+                    int ni = px ? bx1 : bx0 - 1, nj = py ? by1 : by0 - 1; \
+                    float nx = fx, ny = fy; \
+                    if (ni == a.nci) { ni = 0; nx = 0.0f; } \
+                    if (ni < 0) { ni = a.nci - 1; nx = a.xs; } \
+                    if (nj == a.ncj) { nj = 0; ny = 0.0f; } \
+                    if (nj < 0) { nj = a.ncj - 1; ny = a.ys; } \
+                    ci = hit_x ? ni : ci; x = hit_x ? nx : x; \
+                    cj = hit_y ? nj : cj; y = hit_y ? ny : y; \
+                    const int nk = up ? bz1 : bz0 - 1; \
+                    const bool inside = (uint32_t)nk < (uint32_t)a.nck; \
+                    z = hit_z ? fz : z; \
+                    ck = (hit_z && inside) ? nk : ck; \
+                    const bool leave = hit_z && !inside; \
+                    slab += leave ? (up ? 1 : -1) : 0; \
+                    ns = hit ? (leave ? PS_SLAB : PS_TRAVERSE) : PS_COLLIDE; \
+                    if (STATS) ev_trans += hit ? 1u : 0u; \
                 }
 
 // One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, age, slab, cicj,
@@ -757,7 +769,7 @@ constexpr int kPoolBlock = 64;
                     { \
                         age += age_inc; \
                         if (STATS) ++ev_step; \
-                        const float2 mm = a.maj[cb->ncoarse + (uint32_t)slab]; \
+                        const float2 mm = k->maj[cb->ncoarse + (uint32_t)slab]; \
                         const int fi = up ? slab + 1 : slab; \
                         const float fz = fi == 0 ? cb->zface[0] : (fi == 1 ? cb->zface[1] : (fi == 2 ? cb->zface[2] : cb->zface[3])); \
                         const float tz = face_distance(fz, z, (IZ)); \
@@ -765,7 +777,7 @@ constexpr int kPoolBlock = 64;
                         const bool hit = tz <= dn; \
                         const float tt = hit ? tz : dn; \
                         x = fma_((UX), tt, x); y = fma_((UY), tt, y); z = fma_((UZ), tt, z); \
-                        x = wrap_periodic(x, a.xs, cb->inv_xs); y = wrap_periodic(y, a.ys, cb->inv_ys); \
+                        x = wrap_periodic(x, k->xs, cb->inv_xs); y = wrap_periodic(y, k->ys, cb->inv_ys); \
                         if (!hit) \
                         { \
                             ns = PS_COLLIDE; \
@@ -786,26 +798,26 @@ constexpr int kPoolBlock = 64;
                 { \
                     if (slab < 0 || slab >= nslab_) \
                     { \
-                        const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot); \
-                        const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot; \
+                        const int i = cell_of(x, k->inv_dx, k->itot), j = cell_of(y, k->inv_dy, k->jtot); \
+                        const uint32_t ij = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot; \
                         if (slab < 0) \
                         { \
                             if (STATS) ++ev_sfc; \
-                            tally_word = ((DIFFUSE) ? 3u : 2u) * a.ncol + ij; \
+                            tally_word = ((DIFFUSE) ? 3u : 2u) * k->ncol + ij; \
                             slab = 0; \
                             ns = PS_SURFACE; \
                         } \
                         else \
                         { \
                             if (STATS) ++ev_toa; \
-                            tally_word = a.ncol + ij; \
+                            tally_word = k->ncol + ij; \
                             ns = PS_LAUNCH; \
                         } \
                     } \
-                    else if (slab == a.gslab) \
+                    else if (slab == k->gslab) \
                     { \
-                        cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16); \
-                        ck = up ? 0u : (uint32_t)(a.nck - 1); \
+                        cicj = (uint32_t)cell_of(x, k->inv_hx, k->nci) | ((uint32_t)cell_of(y, k->inv_hy, k->ncj) << 16); \
+                        ck = up ? 0u : (uint32_t)(k->nck - 1); \
                         ns = PS_TRAVERSE; \
                     } \
                 }
@@ -825,7 +837,7 @@ constexpr int kPoolBlock = 64;
                 { \
                     const unsigned long long above = lane == 63 ? 0ull : lm >> (lane + 1); \
                     const int run = above ? 1 + __builtin_ctzll(above) : 64 - lane; \
-                    tally_add(&a.tallies[(WORD)], (unsigned long long)run); \
+                    tally_add(&k->tallies[(WORD)], (unsigned long long)run); \
                 } \
             }
 
@@ -873,11 +885,9 @@ rt_trace_pool_kernel(const PoolArgs a)
     {
         // serve the stage with the most photons waiting (ties: traverse, then event); launches
         // (regeneration) once th_launch slots are free or nothing else is left
-        uint32_t cls = (n_t >= n_e && n_t >= n_s) ? 0u : (n_e >= n_s ? 1u : 2u);
-        if (n_x >= RT_TH_SLAB || n_x > max(n_t, max(n_e, n_s)))
-            cls = 4u;
-        if (n_l >= a.th_launch || n_t + n_e + n_s + n_x == 0)
-            cls = 3u;
+        uint32_t cls = ((n_t >= n_e) & (n_t >= n_s)) ? 0u : (n_e >= n_s ? 1u : 2u);
+        cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, max(n_e, n_s)))) ? 4u : cls;
+        cls = ((n_l >= a.th_launch) | (n_t + n_e + n_s + n_x == 0)) ? 3u : cls;
         ++round_ctr;
         const bool tick = (round_ctr & (kTickRounds - 1u)) == 0u;
         const uint32_t age_inc = tick ? kAgeOne : 0u;
@@ -913,7 +923,130 @@ rt_trace_pool_kernel(const PoolArgs a)
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
         uint32_t out_lo = 0u, out_hn = 0u;   // its new ID words (event and launch stages)
 
-        if (cls == 2u)
+        if (cls == 0u)
+        {
+            if (STATS) { ++rounds_t; lanes_t += n; }
+            if (active)
+            {
+                const float4 g0 = R4(0);
+                const float4 g1 = R4(1);
+                const float4 g2 = R4(2);
+                const uint32_t cicj = __float_as_uint(g1.w), cks = __float_as_uint(g2.w);
+                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
+                const float ux = g1.x, uy = g1.y, uz = g1.z;
+                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
+                int slab = (int)((cks >> 16) & 0xffu);
+                uint32_t age = cks & kAgeMask;
+                ns = PS_TRAVERSE;
+                RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
+#if RT_T_STEPS > 1
+                // a lane that crossed a face inside the grid goes on into the next region at once (about half the
+                // lanes of a round do): no selection and no LDS round trip for that step. Measured: 2 steps per
+                // round +0.7 % on C4, +5.5 % on C3; a third gains nothing; asking for a minimum of lanes neither
+#pragma unroll
+                for (int extra = 1; extra < RT_T_STEPS; ++extra)
+                    if (ns == PS_TRAVERSE)
+                    {
+                        RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
+                    }
+#endif
+                R4(0) = make_float4(x, y, z, tau);
+                RW(7) = (uint32_t)ci | ((uint32_t)cj << 16);
+                RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | age;
+            }
+        }
+        else if (cls == 1u)
+        {
+            const ArgPtr k = args_now();
+            if (STATS) { ++rounds_e; lanes_e += n; }
+            // the photon's ID words live in the registers of the lane that owns its slot
+            uint32_t pid_lo = 0u, pn = 0u;
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
+                if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
+            }
+            if (active)
+            {
+                uint32_t cell = 0;
+                float inv_m = 0.0f;
+                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint32_t pid_hi = pn & 0xffu;
+                uint32_t nev = pn >> 8;
+                const uint32_t cks = RW(11);
+                const uint32_t state = (cks >> 26) & 1u ? PS_SURFACE : PS_COLLIDE;
+                {
+                    // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
+                    // dead until the draw below); a photon on the surface has its column from (x, y)
+                    const float4 g0 = R4(0);
+                    const int i = cell_of(g0.x, k->inv_dx, k->itot), j = cell_of(g0.y, k->inv_dy, k->jtot);
+                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
+                    if (state == PS_COLLIDE)
+                    {
+                        inv_m = g0.w;
+                        cell += (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot) * k->ncol;
+                        cr = k->cells[cell];
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                const float kt = cr.x;
+                // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
+                // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
+                // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
+                uint32_t rk0 = key0, rk1 = key1;
+                asm volatile("" : "+s"(rk0), "+s"(rk1));
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
+                ++nev;
+                out_hn = pid_hi | (nev << 8);
+                float tau_new = free_path_tau(u01(w.y));
+                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
+
+                if (state == PS_COLLIDE)
+                {
+                    // collision classification, raytracer_kernels.cu:507-518
+                    if (STATS) ++ev_coll;
+                    const float rr = u01(w.x);
+                    const float p_real = kt * inv_m;
+                    ns = (int)((cks >> 16) & 0xffu) == a.gslab ? PS_TRAVERSE : PS_SLAB;
+                    RW(3) = __float_as_uint(tau_new);
+                    if (rr < p_real)
+                    {
+                        if (STATS) ++ev_real;
+                        const float s_scat = cr.y * p_real;
+                        if (rr <= s_scat)
+                        {
+                            const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
+                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w),
+                                                __uint_as_float((cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u)));
+                            ns = PS_SCATTER;
+                        }
+                        else
+                        {
+                            // absorption, raytracer_kernels.cu:551-566
+                            if (STATS) ++ev_abs;
+                            const bool diffuse = (cks >> 24) & 1u;
+                            tally_add(&k->tallies[5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell]);
+                            ns = PS_LAUNCH;
+                        }
+                    }
+                }
+                else
+                {
+                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
+                    if (u01(w.x) <= cold_of(a)->albedo)
+                    {
+                        tally_add(&k->tallies[4u * k->ncol + cell]);
+                        RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
+                        ns = PS_REFLECT;
+                    }
+                    else
+                        ns = PS_LAUNCH;
+                }
+            }
+        }
+        else if (cls == 2u)
         {
             if (STATS) { ++rounds_s; lanes_s += n; }
             if (active)
@@ -1016,101 +1149,38 @@ rt_trace_pool_kernel(const PoolArgs a)
                 R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24) | age));
             }
         }
-        else if (cls == 1u)
+        else if (__builtin_expect(cls == 4u, 0))
         {
-            if (STATS) { ++rounds_e; lanes_e += n; }
-            // the photon's ID words live in the registers of the lane that owns its slot
-            uint32_t pid_lo = 0u, pn = 0u;
-#pragma unroll
-            for (int h = 0; h < kHalves; ++h)
-            {
-                const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
-                if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
-            }
+            const ArgPtr k = args_now();
+            // ---- slab stage: everything outside the grid ----
+            __builtin_amdgcn_s_setprio(0);
+            if (STATS) { ++rounds_x; lanes_x += n; }
+            const ColdPtr cb = cold_of_k(k);
+            uint32_t tally_word = 0xffffffffu;
             if (active)
             {
-                uint32_t cell = 0;
-                float inv_m = 0.0f;
-                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
-                const uint32_t pid_hi = pn & 0xffu;
-                uint32_t nev = pn >> 8;
+                const float4 g0 = R4(0);
+                const float4 g1 = R4(1);
+                const float iz = __uint_as_float(RW(10));
                 const uint32_t cks = RW(11);
-                const uint32_t state = (cks >> 26) & 1u ? PS_SURFACE : PS_COLLIDE;
-                {
-                    // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
-                    // dead until the draw below); a photon on the surface has its column from (x, y)
-                    const float4 g0 = R4(0);
-                    const int i = cell_of(g0.x, a.inv_dx, a.itot), j = cell_of(g0.y, a.inv_dy, a.jtot);
-                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
-                    if (state == PS_COLLIDE)
-                    {
-                        inv_m = g0.w;
-                        cell += (uint32_t)cell_of(g0.z, a.inv_dz, a.ktot) * a.ncol;
-                        cr = a.cells[cell];
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-                const float kt = cr.x;
-                // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
-                // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
-                // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
-                uint32_t rk0 = key0, rk1 = key1;
-                asm volatile("" : "+s"(rk0), "+s"(rk1));
-                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
-                ++nev;
-                out_hn = pid_hi | (nev << 8);
-                float tau_new = free_path_tau(u01(w.y));
-                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
-
-                if (state == PS_COLLIDE)
-                {
-                    // collision classification, raytracer_kernels.cu:507-518
-                    if (STATS) ++ev_coll;
-                    const float rr = u01(w.x);
-                    const float p_real = kt * inv_m;
-                    ns = (int)((cks >> 16) & 0xffu) == a.gslab ? PS_TRAVERSE : PS_SLAB;
-                    RW(3) = __float_as_uint(tau_new);
-                    if (rr < p_real)
-                    {
-                        if (STATS) ++ev_real;
-                        const float s_scat = cr.y * p_real;
-                        if (rr <= s_scat)
-                        {
-                            const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
-                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w),
-                                                __uint_as_float((cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u)));
-                            ns = PS_SCATTER;
-                        }
-                        else
-                        {
-                            // absorption, raytracer_kernels.cu:551-566
-                            if (STATS) ++ev_abs;
-                            const bool diffuse = (cks >> 24) & 1u;
-                            tally_add(&a.tallies[5u * a.ncol + (diffuse ? a.ncol * (uint32_t)a.ktot : 0u) + cell]);
-                            ns = PS_LAUNCH;
-                        }
-                    }
-                }
-                else
-                {
-                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    if (u01(w.x) <= cold_of(a)->albedo)
-                    {
-                        tally_add(&a.tallies[4u * a.ncol + cell]);
-                        RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
-                        ns = PS_REFLECT;
-                    }
-                    else
-                        ns = PS_LAUNCH;
-                }
+                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
+                int slab = (int)(int8_t)((cks >> 16) & 0xffu);
+                const bool up = iz > 0.0f;
+                uint32_t cicj = 0u, ck = cks & 0xffffu, age = cks & kAgeMask;
+                RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
+                R4(0) = make_float4(x, y, z, tau);
+                if (ns == PS_TRAVERSE)
+                    RW(7) = cicj;
+                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u) | age;
             }
+            RT_SLAB_TALLY(tally_word)
         }
-        else if (__builtin_expect(cls == 3u, 0))
+        else
         {
+            const ArgPtr k = args_now();
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
             __builtin_amdgcn_s_setprio(0);
-            const ColdPtr cb = cold_of(a);
+            const ColdPtr cb = cold_of_k(k);
             while (__builtin_expect(wave_left == 0u && ranges_dry < (uint32_t)kXcds, 0))
             {
                 // next chunk of IDs from this XCD's range (or the next range that has any left): one
@@ -1123,7 +1193,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                 const uint64_t sub_hi = sub_lo + sub < total ? sub_lo + sub : total;
                 unsigned long long c0 = 0;
                 if (lane == 0)
-                    c0 = __hip_atomic_fetch_add(a.cursor + x * kCursorStride, (unsigned long long)chunk,
+                    c0 = __hip_atomic_fetch_add(k->cursor + x * kCursorStride, (unsigned long long)chunk,
                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t c0_lo = __builtin_amdgcn_readfirstlane((uint32_t)c0);
                 const uint32_t c0_hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
@@ -1156,28 +1226,28 @@ rt_trace_pool_kernel(const PoolArgs a)
                 float x, y;
                 if (log2k < 0)
                 {
-                    x = a.xs * u01(w.x);
-                    y = a.ys * u01(w.y);
+                    x = k->xs * u01(w.x);
+                    y = k->ys * u01(w.y);
                 }
                 else
                 {
-                    const uint32_t c = launch_column_index_exact(log2k, a.ncol, my_pid, lk0, lk1);
+                    const uint32_t c = launch_column_index_exact(log2k, k->ncol, my_pid, lk0, lk1);
                     uint32_t ic, jc;
-                    launch_column(cb->div_itot_mul, cb->div_itot_shift, (uint32_t)a.itot, c, ic, jc);
+                    launch_column(cb->div_itot_mul, cb->div_itot_shift, (uint32_t)k->itot, c, ic, jc);
                     const float dx = cb->dx, dy = cb->dy;
                     x = fma_(u01(w.x), dx, (float)ic * dx);
                     y = fma_(u01(w.y), dy, (float)jc * dy);
                 }
-                const int i = cell_of(x, a.inv_dx, a.itot), j = cell_of(y, a.inv_dy, a.jtot);
-                toa_col = (uint32_t)i + (uint32_t)j * (uint32_t)a.itot;
+                const int i = cell_of(x, k->inv_dx, k->itot), j = cell_of(y, k->inv_dy, k->jtot);
+                toa_col = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
                 int slab = cb->nslab - 1;
                 float z = cb->ztop, tau = tau_new;
                 const float sun_x = cb->sun_x, sun_y = cb->sun_y, sun_z = cb->sun_z, iz = cb->inv_sun_z;
                 uint32_t cicj = 0u, ck = 0u, age = 0u;
-                if (slab == a.gslab)
+                if (slab == k->gslab)
                 {
-                    cicj = (uint32_t)cell_of(x, a.inv_hx, a.nci) | ((uint32_t)cell_of(y, a.inv_hy, a.ncj) << 16);
-                    ck = (uint32_t)(a.nck - 1);
+                    cicj = (uint32_t)cell_of(x, k->inv_hx, k->nci) | ((uint32_t)cell_of(y, k->inv_hy, k->ncj) << 16);
+                    ck = (uint32_t)(k->nck - 1);
                     ns = PS_TRAVERSE;
                 }
                 else
@@ -1208,7 +1278,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                 {
                     const unsigned long long above = lane == 63 ? 0ull : lm >> (lane + 1);
                     const int next = above ? lane + 1 + __builtin_ctzll(above) : n_go;
-                    tally_add(&a.tallies[toa_col], (unsigned long long)(next - lane));
+                    tally_add(&k->tallies[toa_col], (unsigned long long)(next - lane));
                 }
             }
 #if RT_FUSE_LAUNCH
@@ -1218,60 +1288,6 @@ rt_trace_pool_kernel(const PoolArgs a)
             const uint32_t adv = (uint32_t)n < wave_left ? (uint32_t)n : wave_left;
             wave_next += adv;
             wave_left -= adv;
-        }
-        else if (__builtin_expect(cls == 4u, 0))
-        {
-            // ---- slab stage: everything outside the grid ----
-            __builtin_amdgcn_s_setprio(0);
-            if (STATS) { ++rounds_x; lanes_x += n; }
-            const ColdPtr cb = cold_of(a);
-            uint32_t tally_word = 0xffffffffu;
-            if (active)
-            {
-                const float4 g0 = R4(0);
-                const float4 g1 = R4(1);
-                const float iz = __uint_as_float(RW(10));
-                const uint32_t cks = RW(11);
-                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                int slab = (int)(int8_t)((cks >> 16) & 0xffu);
-                const bool up = iz > 0.0f;
-                uint32_t cicj = 0u, ck = cks & 0xffffu, age = cks & kAgeMask;
-                RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
-                R4(0) = make_float4(x, y, z, tau);
-                if (ns == PS_TRAVERSE)
-                    RW(7) = cicj;
-                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u) | age;
-            }
-            RT_SLAB_TALLY(tally_word)
-        }
-        else
-        {
-            if (STATS) { ++rounds_t; lanes_t += n; }
-            if (active)
-            {
-                const float4 g0 = R4(0);
-                const float4 g1 = R4(1);
-                const float4 g2 = R4(2);
-                const uint32_t cicj = __float_as_uint(g1.w), cks = __float_as_uint(g2.w);
-                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                const float ux = g1.x, uy = g1.y, uz = g1.z;
-                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
-                int slab = (int)((cks >> 16) & 0xffu);
-                uint32_t age = cks & kAgeMask;
-                ns = PS_TRAVERSE;
-                RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
-#if RT_T_STEPS > 1
-#pragma unroll
-                for (int extra = 1; extra < RT_T_STEPS; ++extra)
-                    if (ns == PS_TRAVERSE)
-                    {
-                        RT_TRAVERSE_STEP(g2.x, g2.y, g2.z, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
-                    }
-#endif
-                R4(0) = make_float4(x, y, z, tau);
-                RW(7) = (uint32_t)ci | ((uint32_t)cj << 16);
-                RW(11) = (uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | age;
-            }
         }
 
 #undef R4
@@ -1307,9 +1323,8 @@ rt_trace_pool_kernel(const PoolArgs a)
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
                   d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
                   d_x = __popcll(__ballot(ncls == 4u));
-        if (cls == 0u) n_t -= n; else if (cls == 1u) n_e -= n; else if (cls == 2u) n_s -= n;
-        else if (cls == 3u) n_l -= n; else n_x -= n;
-        n_t += d_t; n_e += d_e; n_s += d_s; n_l += d_l; n_x += d_x;
+        n_t += d_t - (cls == 0u ? n : 0); n_e += d_e - (cls == 1u ? n : 0); n_s += d_s - (cls == 2u ? n : 0);
+        n_l += d_l - (cls == 3u ? n : 0); n_x += d_x - (cls == 4u ? n : 0);
     }
 
     if (STATS)
@@ -1947,7 +1962,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
 
     const rt_slab_info& sl = c->slabs;
     const float xs = (float)c->itot * c->dx, ys = (float)c->jtot * c->dy;
-    const auto rcp = [](float u) { return std::fmin(std::fmax(1.0f / u, -FLT_MAX), FLT_MAX); };   // dir_reciprocal
+    const auto rcp = [](float u) { return std::fabs(u) >= 0x1p-100f ? 1.0f / u : std::copysign(FLT_MAX, u); };   // dir_reciprocal
     // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
     uint32_t div_shift, div_mul;
     {

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_photon.so")
+# RT_PHOTON_LIB: an experimental build of the library (tools/cmp_libs.sh, kernel experiments); default: the in-tree one
+LIB_PATH = os.environ.get("RT_PHOTON_LIB") or os.path.join(_HERE, "librt_photon.so")
 
 TALLY_NAMES = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up",
                "atmos_direct", "atmos_diffuse")        # file names of raytracer_3d.cu:197-203
