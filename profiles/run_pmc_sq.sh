@@ -15,7 +15,7 @@ for d in ('pmc_sq','pmc_sq2','pmc_tcc'):
     for f in glob.glob('$out/'+d+'/*/*_counter_collection.csv'):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'rt_trace_pool_kernel<false, false' in r['Kernel_Name']:
+            if 'rt_trace_pool_kernel<0, false' in r['Kernel_Name']:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in sorted(agg.items()): print(d, k, len(v), '%.4g' % (sum(v)/len(v)))
 PY

@@ -11,5 +11,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $BENCH > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -5 $out/pmc_fetch.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $BENCH > $out/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -5 $out/pmc_write.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $out/pmc_sq -- $BENCH > $out/pmc_sq.log 2>&1 || { echo "pmc sq failed"; tail -5 $out/pmc_sq.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum --output-format csv -d $out/pmc_tcc -- $BENCH > $out/pmc_tcc.log 2>&1 || { echo "pmc tcc failed"; tail -5 $out/pmc_tcc.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY --output-format csv -d $out/pmc_sq2 -- $BENCH > $out/pmc_sq2.log 2>&1 || { echo "pmc sq2 failed"; tail -5 $out/pmc_sq2.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum --output-format csv -d $out/pmc_tcc -- $BENCH > $out/pmc_tcc.log 2>&1 || { echo "pmc tcc failed"; tail -5 $out/pmc_tcc.log; exit 1; }
 find $out -name '*.csv' | head -40

@@ -22,12 +22,12 @@ for d in sorted(glob.glob(f"{src}/pmc_*/")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            if ("rt_trace_kernel<false, false>" in kn) or ("rt_trace_pool_kernel<false, false" in kn):
+            if ("rt_trace_kernel<false, false>" in kn) or ("rt_trace_pool_kernel<0, false" in kn) or ("rt_trace_pool_kernel<false, false" in kn):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                pmc["vgpr"] = int(r["VGPR_Count"]); pmc["sgpr"] = int(r["SGPR_Count"]); pmc["grid"] = int(r["Grid_Size"])
+                pmc["grid"] = int(r["Grid_Size"])      # (register counts: see the compiler's remark in *_resource_usage.txt)
         for k, v in agg.items():
             pmc[k] = sum(v) / len(v)
-stats = [r for r in csv.DictReader(open(f"{here}/{tag}_kernel_stats.csv")) if ("rt_trace_kernel<false, false>" in r["Name"]) or ("rt_trace_pool_kernel<false, false" in r["Name"])]
+stats = [r for r in csv.DictReader(open(f"{here}/{tag}_kernel_stats.csv")) if ("rt_trace_kernel<false, false>" in r["Name"]) or ("rt_trace_pool_kernel<0, false" in r["Name"]) or ("rt_trace_pool_kernel<false, false" in r["Name"])]
 pmc["kernel_avg_ns"] = float(stats[0]["AverageNs"]); pmc["kernel_calls"] = int(stats[0]["Calls"])
 pmc["photons_per_launch"] = photons
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -40,9 +40,15 @@ if "FETCH_SIZE" in pmc:
     pmc["fabric_reads_per_photon"] = pmc["FETCH_SIZE"] * 1024 / 64 / photons      # 64-byte read requests
 if "TCC_EA0_ATOMIC_sum" in pmc:
     pmc["atomics_per_photon"] = pmc["TCC_EA0_ATOMIC_sum"] / photons
+if "SQ_INSTS_SALU" in pmc:
+    pmc["salu_insts_per_photon"] = pmc["SQ_INSTS_SALU"] / photons
+if "SQ_INSTS_LDS" in pmc and "SQ_LDS_BANK_CONFLICT" in pmc:
+    pmc["lds_insts_per_photon"] = pmc["SQ_INSTS_LDS"] / photons
+    pmc["lds_conflict_cycles_per_lds_inst"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_INSTS_LDS"]
 json.dump(pmc, open(f"{here}/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
 keys = ("photons_per_launch", "launch_log2k", "hbm_bytes_per_launch", "fabric_reads_per_photon", "atomics_per_photon",
-        "valu_wave_insts_per_photon", "active_lanes_per_valu_inst", "kernel_avg_ns")
+        "valu_wave_insts_per_photon", "active_lanes_per_valu_inst", "salu_insts_per_photon", "lds_insts_per_photon",
+        "lds_conflict_cycles_per_lds_inst", "kernel_avg_ns")
 json.dump(dict({k: pmc.get(k) for k in keys}, source=f"profiles/{tag}_pmc.json"),
           open(f"{here}/pmc_{workload}.json", "w"), indent=1)
 print(json.dumps(pmc, indent=1, sort_keys=True))

@@ -65,7 +65,7 @@ elif what == "levels":
     for lv in (0, 1, 2, 3, 4):
         o = dict(base, pool=128, levels=lv); res.append((run(o, 3), lv))
 elif what == "one":
-    o = dict(base, pool=128); res.append((run(o, 5), "default"))
+    o = dict(base); res.append((run(o, 5), "default"))
 elif what == "chunk":
     for ch in (64, 128, 256, 512, 1024, 2048, 4096, 16384):
         o = dict(base, pool=128, chunk=ch); res.append((run(o, 5), ch))
