@@ -121,13 +121,14 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    +-acos(mu) in that plane, the surface reflects to (+-mu, 0, sqrt(1-mu^2))). With
  *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
- *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: 3, 3, 2 with merged
- *                    regions when the launch is stratified or the grid fits the Infinity Cache, else 8, 8, 4 unmerged)
+ *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: the whole number of
+ *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or the grid
+ *                    fits the Infinity Cache, else 8, 8, 4 unmerged)
  *   "levels"         supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
  *                    each crossed as one majorant region, wherever (majorant - mean extinction) * edge length
  *                    <= "merge_tau_milli" / 1000 — the optical depth of null collisions a crossing photon would
  *                    meet (levels = 0: one region per supervoxel; defaults -1 = automatic, 5 or 0 as for the
- *                    supervoxel size, and 2000)
+ *                    supervoxel size, and 1000)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change)

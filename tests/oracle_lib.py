@@ -95,15 +95,18 @@ DEFAULT_SUPERGRID = "auto"        # must equal the product's default (rt_set_opt
 
 
 DEFAULT_LEVELS = "auto"      # the library's defaults of options "levels" and "merge_tau_milli"
-DEFAULT_MERGE_TAU = 2.0
+DEFAULT_MERGE_TAU = 1.0
 
 
 def resolve_auto(scene, supergrid, levels, launch_log2k):
     """The library's automatic choices (build_majorants in rt_photon.hip), restated: fine supervoxels with merged
     regions when the launch is stratified or the packed cells fit the Infinity Cache, else coarse and unmerged."""
     fine = launch_log2k >= 0 or 16 * scene.ncell <= (256 << 20)
+
+    def nearest(target, d):       # whole number of cells nearest to the target length, 1..8
+        return min(max(int(target / float(d) + 0.5), 1), 8)
     if isinstance(supergrid, str):
-        supergrid = (3, 3, 2) if fine else (8, 8, 4)
+        supergrid = (nearest(80.0, scene.dx), nearest(80.0, scene.dy), nearest(50.0, scene.dz)) if fine else (8, 8, 4)
     if isinstance(levels, str):
         levels = 5 if fine else 0
     return supergrid, levels

@@ -114,13 +114,17 @@ def test_statistical_parity_with_cpu_ref(name):
         m = (xa + xb) >= 20
         pooled = (xa + xb) / (na + nb)
         return ((xa / na - xb / nb) / np.sqrt(pooled * (1 / na + 1 / nb)))[m]
+    def gate(z):
+        # mean(z^2) of N standard normal z-scores scatters by sqrt(2 / N) around 1: 0.15, or 3.5 of those if larger
+        # (the tiny scene has 160 level-by-row bins only)
+        return abs(np.mean(z ** 2) - 1.0) < max(0.15, 3.5 * np.sqrt(2.0 / z.size))
     for t in ("surface_down_direct", "surface_down_diffuse", "toa_up"):
         z = zscores(a[t], b[t])
-        assert z.size > 50 and np.max(np.abs(z)) < 6.0 and 0.85 < np.mean(z ** 2) < 1.15, (t, np.mean(z ** 2))
+        assert z.size > 50 and np.max(np.abs(z)) < 6.0 and gate(z), (t, np.mean(z ** 2))
     atm_a = (a["atmos_direct"] + a["atmos_diffuse"]).sum(axis=2)
     atm_b = (b["atmos_direct"] + b["atmos_diffuse"]).sum(axis=2)
     z = zscores(atm_a, atm_b)
-    assert np.max(np.abs(z)) < 6.0 and 0.85 < np.mean(z ** 2) < 1.15, np.mean(z ** 2)
+    assert np.max(np.abs(z)) < 6.0 and gate(z), (np.mean(z ** 2), z.size)
 
 
 def test_fixed_dot_changes_and_conserves():

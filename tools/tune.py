@@ -58,6 +58,11 @@ elif what == "merge3":
         for tau in (1000, 2000, 3000):
             o = dict(base, pool=128, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
             res.append((run(o, 3),) + sg + (lv, tau))
+elif what == "merge4":
+    for sg, lv in (((3, 3, 2), 5), ((2, 2, 2), 5), ((3, 3, 1), 5), ((2, 2, 1), 6)):
+        for tau in (250, 500, 750, 1000, 1250, 1500):
+            o = dict(base, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
+            res.append((run(o, 3),) + sg + (lv, tau))
 elif what == "thl":
     for thl in (16, 24, 32, 40, 48, 64):
         o = dict(base, pool=128, th_launch=thl); res.append((run(o, 3), thl))
