@@ -685,13 +685,20 @@ constexpr uint32_t kTickRounds = 1u << 17;
 #define RT_PRIO 1
 #endif
 #ifndef RT_TH_SLAB
-#define RT_TH_SLAB 16       // photons waiting for the slab stage that get it served ahead of the larger stages
+#define RT_TH_SLAB 24       // photons waiting for the slab stage that get it served ahead of the larger stages
 #endif
 // traverse steps a lane may take in one round of the traverse stage (a lane that crossed a face inside the grid
 // goes on into the next region at once instead of waiting for the next round)
 // the default pool size: the one instantiated without the event counters as well (the others always count)
 #ifndef RT_FAST_POOL
 #define RT_FAST_POOL 128
+#endif
+// event, new direction and the next traverse step in one round (no new-direction stage); 0: three stages
+#ifndef RT_FUSE_SCATTER
+#define RT_FUSE_SCATTER 1
+#endif
+#ifndef RT_E_T_STEPS
+#define RT_E_T_STEPS 1      // traverse steps at the end of the fused event round
 #endif
 #ifndef RT_T_STEPS
 #define RT_T_STEPS 2
@@ -773,6 +780,73 @@ constexpr int kPoolBlock = 64;
                     slab += leave ? (up ? 1 : -1) : 0; \
                     ns = hit ? (leave ? PS_SLAB : PS_TRAVERSE) : PS_COLLIDE; \
                     if (STATS) ev_trans += hit ? 1u : 0u; \
+                }
+
+// The new direction of a photon that scatters (phase function + rotation, raytracer_kernels.cu:520-548) or is
+// reflected by the surface (Lambert, :467-473), in place on the lane's locals ux, uy, uz. REFLECT / FROM_CLOUD say
+// which; ASY is the cell's asymmetry, UMU and UPHI the two uniform draws. PLANAR: the 2D tracer's rules
+// (raytracer.cpp:360-364, 280-282): turn the direction by +-acos(mu) within the x-z plane (angle-sum formulas
+// instead of acos/atan2/sin/cos), reflect to (+-mu, 0, sqrt(1 - mu^2)); the sign is the top bit of the azimuth draw.
+#define RT_NEW_DIRECTION(REFLECT, FROM_CLOUD, ASY, UMU, UPHI) \
+                if (PLANAR) \
+                { \
+                    const bool plus = (UPHI) >= 0.5f; \
+                    if (!(REFLECT)) \
+                    { \
+                        const float mu = (FROM_CLOUD) ? henyey_mu((ASY), (UMU)) : rayleigh_mu((UMU)); \
+                        const float sn2 = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f), 0.0f)); \
+                        const float ssn = plus ? sn2 : -sn2; \
+                        const float nx = fma_(mu, ux, ssn * uz); \
+                        const float nz = fma_(mu, uz, -(ssn * ux)); \
+                        ux = nx; uz = nz; \
+                    } \
+                    else \
+                    { \
+                        const float mu = rt_sqrt((UMU)); \
+                        ux = plus ? mu : -mu; \
+                        uz = rt_sqrt(fma_(-mu, mu, 1.0f)); \
+                    } \
+                    uy = 0.0f; \
+                } \
+                else \
+                { \
+                    float sp, cp; \
+                    rt_sincos2pi((UPHI), sp, cp); \
+                    if (!(REFLECT)) \
+                    { \
+                        const float mu = (FROM_CLOUD) ? henyey_mu((ASY), (UMU)) : rayleigh_mu((UMU)); \
+                        const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f)); \
+                        float ax = 0.0f, ay = 0.0f, az = 0.0f; \
+                        const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz); \
+                        if (fx < fy) \
+                        { \
+                            if (fx < fz) ax = 1.0f; else az = 1.0f; \
+                        } \
+                        else \
+                        { \
+                            if (fy < fz) ay = 1.0f; else az = 1.0f; \
+                        } \
+                        /* dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73) */ \
+                        const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux)) \
+                                                     : fma_(az, az, fma_(ay, uy, ax * ux)); \
+                        float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az); \
+                        const float inv_len = rt_rcp(rt_sqrt(fma_(oz, oz, fma_(oy, oy, ox * ox)))); \
+                        ox *= inv_len; oy *= inv_len; oz *= inv_len; \
+                        const float bx = fma_(uy, oz, -(uz * oy)); \
+                        const float by = fma_(uz, ox, -(ux * oz)); \
+                        const float bz = fma_(ux, oy, -(uy * ox)); \
+                        const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx)); \
+                        const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by)); \
+                        const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz)); \
+                        ux = nx; uy = ny; uz = nz; \
+                    } \
+                    else \
+                    { \
+                        const float mu = rt_sqrt((UMU)); \
+                        ux = mu * sp; \
+                        uy = mu * cp; \
+                        uz = rt_sqrt(fma_(-mu, mu, 1.0f) + RT_EPS); \
+                    } \
                 }
 
 // One visit of the slab stage on the photon held in the lane's locals (x, y, z, tau, age, slab, cicj,
@@ -918,8 +992,13 @@ rt_trace_pool_kernel(const PoolArgs a)
         // (regeneration) once th_launch slots are free or nothing else is left
         // (fullest first is the optimum: asking the dearer stages -- new direction, event -- to be 1/8 or 1/4 fuller
         // than the others before they are served, or less full, loses 0.4 .. 1.8 % on C4 and C3)
+#if RT_FUSE_SCATTER
+        uint32_t cls = n_t >= n_e ? 0u : 1u;                 // (no photon ever waits for a new-direction stage)
+        cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, n_e))) ? 4u : cls;
+#else
         uint32_t cls = ((n_t >= n_e) & (n_t >= n_s)) ? 0u : (n_e >= n_s ? 1u : 2u);
         cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, max(n_e, n_s)))) ? 4u : cls;
+#endif
         cls = ((n_l >= a.th_launch) | (n_t + n_e + n_s + n_x == 0)) ? 3u : cls;
         ++round_ctr;
         const bool tick = (round_ctr & (kTickRounds - 1u)) == 0u;
@@ -1000,6 +1079,134 @@ rt_trace_pool_kernel(const PoolArgs a)
                 const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
                 if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
             }
+#if RT_FUSE_SCATTER
+            // Event, new direction and the photon's next traverse step in ONE round. A photon that scatters (two
+            // thirds of the collision tests of the cumulus scenes) or is reflected gets its new direction here, from
+            // the cell record and the draws that are in registers anyway, and every photon that lives on -- scattered,
+            // reflected, or after a null collision -- takes its next traverse step at once (it stays in the region it
+            // is in; that region's majorant is asked for together with the cell record). No new-direction stage: its
+            // rounds (a quarter of all), their slot selection, record round trips and stage counts are gone, and
+            // the pool's photons wait for two frequent stages instead of three, so rounds are fuller.
+            if (active)
+            {
+                uint32_t cell = 0;
+                float inv_m = 0.0f;
+                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
+                const uint32_t pid_hi = pn & 0xffu;
+                uint32_t nev = pn >> 8;
+                const float4 g0 = R4(0);
+                const float4 g1 = R4(1);
+                const float4 g2 = R4(2);
+                const uint32_t cicj = __float_as_uint(g1.w), cks = __float_as_uint(g2.w);
+                const bool on_surface = (cks >> 26) & 1u;          // surface event, not collision (set by the slab stage)
+                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
+                int slab = (int)((cks >> 16) & 0xffu);
+                uint32_t age = cks & kAgeMask;
+                float2 mm_pre = make_float2(0.0f, 0.0f);
+                {
+                    // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
+                    // dead until the draw below); a photon on the surface has its column from (x, y)
+                    const int i = cell_of(g0.x, k->inv_dx, k->itot), j = cell_of(g0.y, k->inv_dy, k->jtot);
+                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
+                    if (!on_surface)
+                    {
+                        inv_m = g0.w;
+                        const uint32_t kz = (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot);
+                        cr = k->cells[brick_index((uint32_t)i, (uint32_t)j, kz, k->nbi, k->nbij)];
+                        cell += kz * k->ncol;           // the [k][j][i] index, for the absorption tally
+                    }
+                    if (slab == a.gslab)
+                        mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
+                }
+                __builtin_amdgcn_s_setprio(0);
+                const float kt = cr.x;
+                // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
+                // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
+                // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
+                uint32_t rk0 = key0, rk1 = key1;
+                asm volatile("" : "+s"(rk0), "+s"(rk1));
+                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
+                ++nev;
+                out_hn = pid_hi | (nev << 8);
+                float tau_new = free_path_tau(u01(w.y));
+                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
+
+                bool alive = true, turn = false, reflect = false, from_cloud = false;
+                float u_mu = 0.0f, u_phi = 0.0f;
+                if (!on_surface)
+                {
+                    // collision classification, raytracer_kernels.cu:507-518
+                    if (STATS) ++ev_coll;
+                    const float rr = u01(w.x);
+                    const float p_real = kt * inv_m;
+                    if (rr < p_real)
+                    {
+                        if (STATS) ++ev_real;
+                        const float s_scat = cr.y * p_real;
+                        if (rr <= s_scat)
+                        {
+                            from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
+                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                            turn = true; u_mu = u01(w.z); u_phi = u01(w.w);
+                        }
+                        else
+                        {
+                            // absorption, raytracer_kernels.cu:551-566
+                            if (STATS) ++ev_abs;
+                            const bool diffuse = (cks >> 24) & 1u;
+                            tally_add(&k->tallies[5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell]);
+                            ns = PS_LAUNCH;
+                            alive = false;
+                        }
+                    }
+                }
+                else
+                {
+                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
+                    if (u01(w.x) <= cold_of(a)->albedo)
+                    {
+                        tally_add(&k->tallies[4u * k->ncol + cell]);
+                        turn = reflect = true; u_mu = u01(w.y); u_phi = u01(w.z);
+                    }
+                    else
+                    {
+                        ns = PS_LAUNCH;
+                        alive = false;
+                    }
+                }
+                if (alive)
+                {
+                    float x = g0.x, y = g0.y, z = g0.z;
+                    float tau = on_surface ? g0.w : tau_new;        // a reflected photon keeps its optical depth
+                    float ux = g1.x, uy = g1.y, uz = g1.z, ix = g2.x, iy = g2.y, iz = g2.z;
+                    uint32_t diffuse_bit = cks & (1u << 24);
+                    if (turn)
+                    {
+                        RT_NEW_DIRECTION(reflect, from_cloud, cr.z, u_mu, u_phi)
+                        ix = dir_reciprocal(ux); iy = dir_reciprocal(uy); iz = dir_reciprocal(uz);
+                        diffuse_bit = 1u << 24;
+                    }
+                    if (slab == a.gslab)
+                    {
+                        RT_TRAVERSE_STEP(ix, iy, iz, mm_pre)
+#if RT_E_T_STEPS > 1
+#pragma unroll
+                        for (int extra = 1; extra < RT_E_T_STEPS; ++extra)
+                            if (ns == PS_TRAVERSE)
+                            {
+                                RT_TRAVERSE_STEP(ix, iy, iz, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
+                            }
+#endif
+                    }
+                    else
+                        ns = PS_SLAB;
+                    R4(0) = make_float4(x, y, z, tau);
+                    R4(1) = make_float4(ux, uy, uz, __uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)));
+                    R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | diffuse_bit | age));
+                }
+            }
+        }
+#else
             if (active)
             {
                 uint32_t cell = 0;
@@ -1080,6 +1287,8 @@ rt_trace_pool_kernel(const PoolArgs a)
                 }
             }
         }
+#endif
+#if !RT_FUSE_SCATTER
         else if (cls == 2u)
         {
             if (STATS) { ++rounds_s; lanes_s += n; }
@@ -1100,73 +1309,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                     mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
                 __builtin_amdgcn_s_setprio(0);
                 float ux = g1.x, uy = g1.y, uz = g1.z;
-                if (PLANAR)
-                {
-                    // the 2D tracer's rules (raytracer.cpp:360-364, 280-282): turn the direction by
-                    // +-acos(mu) within the x-z plane (angle-sum formulas instead of acos/atan2/sin/cos),
-                    // reflect to (+-mu, 0, sqrt(1 - mu^2)); the sign is the top bit of the azimuth draw
-                    const bool plus = g2.z >= 0.5f;
-                    if (state == PS_SCATTER)
-                    {
-                        const bool from_cloud = (cks >> 25) & 1u;
-                        const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
-                        const float sn2 = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f), 0.0f));
-                        const float ssn = plus ? sn2 : -sn2;
-                        const float nx = fma_(mu, ux, ssn * uz);
-                        const float nz = fma_(mu, uz, -(ssn * ux));
-                        ux = nx; uz = nz;
-                    }
-                    else
-                    {
-                        const float mu = rt_sqrt(g2.y);
-                        ux = plus ? mu : -mu;
-                        uz = rt_sqrt(fma_(-mu, mu, 1.0f));
-                    }
-                    uy = 0.0f;
-                }
-                else
-                {
-                    float sp, cp;
-                    rt_sincos2pi(g2.z, sp, cp);
-                    if (state == PS_SCATTER)
-                    {
-                        // phase function + rotation, raytracer_kernels.cu:520-548
-                        const bool from_cloud = (cks >> 25) & 1u;
-                        const float mu = from_cloud ? henyey_mu(g2.x, g2.y) : rayleigh_mu(g2.y);
-                        const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f));
-                        float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                        const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz);
-                        if (fx < fy)
-                        {
-                            if (fx < fz) ax = 1.0f; else az = 1.0f;
-                        }
-                        else
-                        {
-                            if (fy < fz) ay = 1.0f; else az = 1.0f;
-                        }
-                        // dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73)
-                        const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux))
-                                                     : fma_(az, az, fma_(ay, uy, ax * ux));
-                        float ox = fma_(-proj, ux, ax), oy = fma_(-proj, uy, ay), oz = fma_(-proj, uz, az);
-                        const float inv_len = rt_rcp(rt_sqrt(fma_(oz, oz, fma_(oy, oy, ox * ox))));
-                        ox *= inv_len; oy *= inv_len; oz *= inv_len;
-                        const float bx = fma_(uy, oz, -(uz * oy));
-                        const float by = fma_(uz, ox, -(ux * oz));
-                        const float bz = fma_(ux, oy, -(uy * ox));
-                        const float nx = fma_(mu, ux, sn * fma_(sp, ox, cp * bx));
-                        const float ny = fma_(mu, uy, sn * fma_(sp, oy, cp * by));
-                        const float nz = fma_(mu, uz, sn * fma_(sp, oz, cp * bz));
-                        ux = nx; uy = ny; uz = nz;
-                    }
-                    else
-                    {
-                        // Lambertian reflection, raytracer_kernels.cu:467-473
-                        const float mu = rt_sqrt(g2.y);
-                        ux = mu * sp;
-                        uy = mu * cp;
-                        uz = rt_sqrt(fma_(-mu, mu, 1.0f) + RT_EPS);
-                    }
-                }
+                RT_NEW_DIRECTION(state == PS_REFLECT, (cks >> 25) & 1u, g2.x, g2.y, g2.z)
                 // diffuse from now on; then the photon's next traverse step at once
                 const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
                 const float4 g0 = R4(0);
@@ -1183,6 +1326,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                 R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24) | age));
             }
         }
+#endif
         else if (__builtin_expect(cls == 4u, 0))
         {
             const ArgPtr k = args_now();
@@ -1355,7 +1499,7 @@ rt_trace_pool_kernel(const PoolArgs a)
         // ---- update the stage counts ----
         const uint32_t ncls = active ? (ns >> 2) : 5u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
-                  d_s = __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
+                  d_s = RT_FUSE_SCATTER ? 0 : __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
                   d_x = __popcll(__ballot(ncls == 4u));
         n_t += d_t - (cls == 0u ? n : 0); n_e += d_e - (cls == 1u ? n : 0); n_s += d_s - (cls == 2u ? n : 0);
         n_l += d_l - (cls == 3u ? n : 0); n_x += d_x - (cls == 4u ? n : 0);
