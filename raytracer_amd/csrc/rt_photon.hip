@@ -697,9 +697,6 @@ constexpr uint32_t kTickRounds = 1u << 17;
 #ifndef RT_FUSE_SCATTER
 #define RT_FUSE_SCATTER 1
 #endif
-#ifndef RT_E_T_STEPS
-#define RT_E_T_STEPS 1      // traverse steps at the end of the fused event round
-#endif
 #ifndef RT_T_STEPS
 #define RT_T_STEPS 2
 #endif
@@ -1189,14 +1186,8 @@ rt_trace_pool_kernel(const PoolArgs a)
                     if (slab == a.gslab)
                     {
                         RT_TRAVERSE_STEP(ix, iy, iz, mm_pre)
-#if RT_E_T_STEPS > 1
-#pragma unroll
-                        for (int extra = 1; extra < RT_E_T_STEPS; ++extra)
-                            if (ns == PS_TRAVERSE)
-                            {
-                                RT_TRAVERSE_STEP(ix, iy, iz, a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)])
-                            }
-#endif
+                        // (a second traverse step here, for the lanes that crossed a face, costs 6 %: the round is
+                        // long as it is, and its registers decide the kernel's count)
                     }
                     else
                         ns = PS_SLAB;
