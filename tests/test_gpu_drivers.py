@@ -135,6 +135,24 @@ def test_zenith_and_azimuth_sweep(tmp_path):
     assert (tmp_path / "azimuth_090" / "atmos_direct.bin").exists() and (tmp_path / "azimuth_270" / "checkpoint").exists()
 
 
+def test_io_driver_at_its_default_grid_with_a_zenith_sweep(tmp_path):
+    """BASELINE config 5 at the grid raytracer_3d_io.cu:11-17 compiles in (240 x 240 x 284 cells of 100/100/30 m): no
+    dimension options, no sidecar, four headerless float32 files of 65 MB each, two solar zenith angles with the
+    full 3D absorption output per run; bit-identical to the oracle."""
+    sc = scenes.cumulus(240, 240, 284, 100.0, 100.0, 30.0, n_clouds=60, seed=7, z_base=900.0, z_top=3000.0,
+                        name="io_default_grid")
+    sc.write(str(tmp_path), sidecar=False)
+    r = subprocess.run([IO, "20", "--seed=6", "--zenith=20,65"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for zen in (20, 65):
+        sc.zenith_deg = float(zen)
+        want, _ = O.photon_oracle(sc, 6, 0, 1 << 20)
+        got = _read(tmp_path / f"zenith_{zen:02d}", sc)
+        for n in TALLY_NAMES:
+            assert np.array_equal(got[n], want[n]), (zen, n)
+        assert O.balance(got) == 0 and got["atmos_direct"].shape == (284, 240, 240)
+
+
 def test_stratified_launch_option_of_the_drivers(tmp_path):
     """--launch=auto picks the largest K <= 5 with whole passes of ncol * 2^K photons; --launch=K is explicit."""
     sc = scenes.tiny()

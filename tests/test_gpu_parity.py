@@ -103,6 +103,22 @@ def test_device_math_is_bit_identical_to_oracle(rt):
     assert np.max(np.abs(got - np.log(x))) < 2e-6
 
 
+def test_device_samplers_are_bit_identical_to_oracle(rt):
+    """rt_selftest_math cases 4 and 5: the Rayleigh cosine and the Henyey-Greenstein cosine (g = 0.85) of a uniform
+    draw, device against oracle, bit for bit over the 2^-24 lattice."""
+    lib = rt.load_library()
+    ol = O.lib()
+    u = (np.arange(0, 1 << 24, 521, dtype=np.uint32)).astype(np.float32) * np.float32(2.0 ** -24)
+    for which, fn in ((4, lambda v: ol.oracle_rayleigh_mu(v)), (5, lambda v: ol.oracle_henyey_mu(0.85, v))):
+        got = np.zeros_like(u)
+        assert lib.rt_selftest_math(0, which, u.ctypes.data_as(C.POINTER(C.c_float)), u.size,
+                                    got.ctypes.data_as(C.POINTER(C.c_float))) == 0, lib.rt_last_error()
+        want = np.array([fn(float(v)) for v in u], dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), which
+        assert np.abs(got).max() <= 1.0 + 1e-5
+    assert abs(float(got.astype(np.float64).mean()) - 0.85) < 1e-3           # <mu>_HG = g
+
+
 SCENES = {
     "tiny": lambda S: S.tiny(),
     "block_cloud": lambda S: S.block_cloud(),
