@@ -670,7 +670,8 @@ rt_trace_kernel(const TraceArgs a)
 // valid run ends after tens of steps and at most a handful of ticks can pass in a wave's whole life (a launch of
 // 2^28 photons is about 2 * 10^4 rounds per wave), so the guard cannot fire on one. Non-finite positions are
 // caught in the step itself, at once.
-enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_SCATTER = 8, PS_REFLECT = 9, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
+// (state >> 2 is the stage that serves it: 0 traverse, 1 event, 3 launch, 4 slab; class 2 was round 1's new-direction stage)
+enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
 enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
 constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
@@ -692,10 +693,6 @@ constexpr uint32_t kTickRounds = 1u << 17;
 // the default pool size: the one instantiated without the event counters as well (the others always count)
 #ifndef RT_FAST_POOL
 #define RT_FAST_POOL 128
-#endif
-// event, new direction and the next traverse step in one round (no new-direction stage); 0: three stages
-#ifndef RT_FUSE_SCATTER
-#define RT_FUSE_SCATTER 1
 #endif
 #ifndef RT_T_STEPS
 #define RT_T_STEPS 2
@@ -972,7 +969,7 @@ rt_trace_pool_kernel(const PoolArgs a)
 #pragma unroll
     for (int h = 0; h < kHalves; ++h)
         stv[h] = (h * 64 + lane < NS) ? PS_LAUNCH : PS_DONE;
-    int n_t = 0, n_e = 0, n_s = 0, n_x = 0, n_l = NS;     // photons waiting per stage (wave-uniform)
+    int n_t = 0, n_e = 0, n_x = 0, n_l = NS;              // photons waiting per stage (wave-uniform)
     // photon ID words of the slots this lane owns (slot h * 64 + lane): {pid_lo, pid_hi | nev << 8}. Only the
     // event and launch stages touch them; keeping them out of LDS is what lets 26 waves share a CU
     uint32_t id_lo[kHalves], id_hn[kHalves];
@@ -981,22 +978,17 @@ rt_trace_pool_kernel(const PoolArgs a)
 
     uint32_t ev_step = 0, ev_coll = 0, ev_real = 0, ev_scat = 0, ev_cscat = 0, ev_sfc = 0, ev_toa = 0,
              ev_abs = 0, ev_trans = 0;
-    uint32_t rounds_t = 0, rounds_e = 0, rounds_s = 0, lanes_t = 0, lanes_e = 0, lanes_s = 0, rounds_x = 0, lanes_x = 0;
+    uint32_t rounds_t = 0, rounds_e = 0, lanes_t = 0, lanes_e = 0, rounds_x = 0, lanes_x = 0;
 
-    while (n_t + n_e + n_s + n_x + n_l > 0)
+    while (n_t + n_e + n_x + n_l > 0)
     {
         // serve the stage with the most photons waiting (ties: traverse, then event); launches
         // (regeneration) once th_launch slots are free or nothing else is left
         // (fullest first is the optimum: asking the dearer stages -- new direction, event -- to be 1/8 or 1/4 fuller
         // than the others before they are served, or less full, loses 0.4 .. 1.8 % on C4 and C3)
-#if RT_FUSE_SCATTER
-        uint32_t cls = n_t >= n_e ? 0u : 1u;                 // (no photon ever waits for a new-direction stage)
+        uint32_t cls = n_t >= n_e ? 0u : 1u;
         cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, n_e))) ? 4u : cls;
-#else
-        uint32_t cls = ((n_t >= n_e) & (n_t >= n_s)) ? 0u : (n_e >= n_s ? 1u : 2u);
-        cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, max(n_e, n_s)))) ? 4u : cls;
-#endif
-        cls = ((n_l >= a.th_launch) | (n_t + n_e + n_s + n_x == 0)) ? 3u : cls;
+        cls = ((n_l >= a.th_launch) | (n_t + n_e + n_x == 0)) ? 3u : cls;
         ++round_ctr;
         const bool tick = (round_ctr & (kTickRounds - 1u)) == 0u;
         const uint32_t age_inc = tick ? kAgeOne : 0u;
@@ -1076,7 +1068,6 @@ rt_trace_pool_kernel(const PoolArgs a)
                 const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
                 if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
             }
-#if RT_FUSE_SCATTER
             // Event, new direction and the photon's next traverse step in ONE round. A photon that scatters (two
             // thirds of the collision tests of the cumulus scenes) or is reflected gets its new direction here, from
             // the cell record and the draws that are in registers anyway, and every photon that lives on -- scattered,
@@ -1197,127 +1188,6 @@ rt_trace_pool_kernel(const PoolArgs a)
                 }
             }
         }
-#else
-            if (active)
-            {
-                uint32_t cell = 0;
-                float inv_m = 0.0f;
-                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
-                const uint32_t pid_hi = pn & 0xffu;
-                uint32_t nev = pn >> 8;
-                const uint32_t cks = RW(11);
-                const uint32_t state = (cks >> 26) & 1u ? PS_SURFACE : PS_COLLIDE;
-                {
-                    // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
-                    // dead until the draw below); a photon on the surface has its column from (x, y)
-                    const float4 g0 = R4(0);
-                    const int i = cell_of(g0.x, k->inv_dx, k->itot), j = cell_of(g0.y, k->inv_dy, k->jtot);
-                    cell = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
-                    if (state == PS_COLLIDE)
-                    {
-                        inv_m = g0.w;
-                        const uint32_t kz = (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot);
-                        cr = k->cells[brick_index((uint32_t)i, (uint32_t)j, kz, k->nbi, k->nbij)];
-                        cell += kz * k->ncol;           // the [k][j][i] index, for the absorption tally
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-                const float kt = cr.x;
-                // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
-                // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
-                // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
-                uint32_t rk0 = key0, rk1 = key1;
-                asm volatile("" : "+s"(rk0), "+s"(rk1));
-                const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
-                ++nev;
-                out_hn = pid_hi | (nev << 8);
-                float tau_new = free_path_tau(u01(w.y));
-                tau_new = tau_new > 0.0f ? tau_new : 0.0f;
-
-                if (state == PS_COLLIDE)
-                {
-                    // collision classification, raytracer_kernels.cu:507-518
-                    if (STATS) ++ev_coll;
-                    const float rr = u01(w.x);
-                    const float p_real = kt * inv_m;
-                    ns = (int)((cks >> 16) & 0xffu) == a.gslab ? PS_TRAVERSE : PS_SLAB;
-                    RW(3) = __float_as_uint(tau_new);
-                    if (rr < p_real)
-                    {
-                        if (STATS) ++ev_real;
-                        const float s_scat = cr.y * p_real;
-                        if (rr <= s_scat)
-                        {
-                            const bool from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
-                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            R4(2) = make_float4(cr.z, u01(w.z), u01(w.w),
-                                                __uint_as_float((cks & ~(1u << 25)) | (from_cloud ? 1u << 25 : 0u)));
-                            ns = PS_SCATTER;
-                        }
-                        else
-                        {
-                            // absorption, raytracer_kernels.cu:551-566
-                            if (STATS) ++ev_abs;
-                            const bool diffuse = (cks >> 24) & 1u;
-                            tally_add(&k->tallies[5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell]);
-                            ns = PS_LAUNCH;
-                        }
-                    }
-                }
-                else
-                {
-                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    if (u01(w.x) <= cold_of(a)->albedo)
-                    {
-                        tally_add(&k->tallies[4u * k->ncol + cell]);
-                        RW(9) = __float_as_uint(u01(w.y)); RW(10) = __float_as_uint(u01(w.z));
-                        ns = PS_REFLECT;
-                    }
-                    else
-                        ns = PS_LAUNCH;
-                }
-            }
-        }
-#endif
-#if !RT_FUSE_SCATTER
-        else if (cls == 2u)
-        {
-            if (STATS) { ++rounds_s; lanes_s += n; }
-            if (active)
-            {
-                const float4 g1 = R4(1);
-                const float4 g2 = R4(2);                     // {asy, u_mu, u_phi, cks}
-                const uint32_t cks = __float_as_uint(g2.w);
-                const uint32_t state = (cks >> 26) & 1u ? PS_REFLECT : PS_SCATTER;
-                // the majorant of the photon's region for the traverse step at the end of this stage: asked for
-                // now, so that the scattering arithmetic runs while the gather is under way
-                const uint32_t cicj = __float_as_uint(g1.w);
-                int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
-                int slab = (int)((cks >> 16) & 0xffu);
-                uint32_t age = cks & kAgeMask;
-                float2 mm_pre = make_float2(0.0f, 0.0f);
-                if (slab == a.gslab)
-                    mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
-                __builtin_amdgcn_s_setprio(0);
-                float ux = g1.x, uy = g1.y, uz = g1.z;
-                RT_NEW_DIRECTION(state == PS_REFLECT, (cks >> 25) & 1u, g2.x, g2.y, g2.z)
-                // diffuse from now on; then the photon's next traverse step at once
-                const float ix = dir_reciprocal(ux), iy = dir_reciprocal(uy), iz = dir_reciprocal(uz);
-                const float4 g0 = R4(0);
-                float x = g0.x, y = g0.y, z = g0.z, tau = g0.w;
-                if (slab == a.gslab)
-                {
-                    ns = PS_TRAVERSE;
-                    RT_TRAVERSE_STEP(ix, iy, iz, mm_pre)
-                }
-                else
-                    ns = PS_SLAB;
-                R4(0) = make_float4(x, y, z, tau);
-                R4(1) = make_float4(ux, uy, uz, __uint_as_float((uint32_t)ci | ((uint32_t)cj << 16)));
-                R4(2) = make_float4(ix, iy, iz, __uint_as_float((uint32_t)ck | (((uint32_t)slab & 0xffu) << 16) | (1u << 24) | age));
-            }
-        }
-#endif
         else if (__builtin_expect(cls == 4u, 0))
         {
             const ArgPtr k = args_now();
@@ -1490,9 +1360,8 @@ rt_trace_pool_kernel(const PoolArgs a)
         // ---- update the stage counts ----
         const uint32_t ncls = active ? (ns >> 2) : 5u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
-                  d_s = RT_FUSE_SCATTER ? 0 : __popcll(__ballot(ncls == 2u)), d_l = __popcll(__ballot(ncls == 3u)),
-                  d_x = __popcll(__ballot(ncls == 4u));
-        n_t += d_t - (cls == 0u ? n : 0); n_e += d_e - (cls == 1u ? n : 0); n_s += d_s - (cls == 2u ? n : 0);
+                  d_l = __popcll(__ballot(ncls == 3u)), d_x = __popcll(__ballot(ncls == 4u));
+        n_t += d_t - (cls == 0u ? n : 0); n_e += d_e - (cls == 1u ? n : 0);
         n_l += d_l - (cls == 3u ? n : 0); n_x += d_x - (cls == 4u ? n : 0);
     }
 
@@ -1507,7 +1376,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                                        __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0)
         {
-            const uint32_t sch[8] = {rounds_t, rounds_e, rounds_s, lanes_t, lanes_e, lanes_s, rounds_x, lanes_x};
+            const uint32_t sch[8] = {rounds_t, rounds_e, 0u, lanes_t, lanes_e, 0u, rounds_x, lanes_x};
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 __hip_atomic_fetch_add(&events[RT_N_EVENTS + e], (unsigned long long)sch[e], __ATOMIC_RELAXED,
