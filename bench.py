@@ -252,7 +252,8 @@ def main():
                        "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}",
                        "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, "
                                   f"{n_per_gpu // ((scene.itot * scene.jtot) << launch_log2k)} sweeps of the domain top per GPU per step"
-                                  if launch_log2k >= 0 else "uniform random positions")},
+                                  if launch_log2k >= 0 else "uniform random positions (the reference's sampling); photon ids taken in the order "
+                                  "of their launch tile -- sorted on the device inside the timed region, kernel_ms includes the sort's passes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "rt_trace_pool_kernel", "kernel_ms": avg_kernel_ms,

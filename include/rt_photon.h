@@ -122,8 +122,8 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
  *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: the whole number of
- *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or the grid
- *                    fits the Infinity Cache, else 8, 8, 4 unmerged)
+ *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or sorted
+ *                    or the grid fits the Infinity Cache, else 8, 8, 4 unmerged)
  *   "levels"         supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
  *                    each crossed as one majorant region, wherever (majorant - mean extinction) * edge length
  *                    <= "merge_tau_milli" / 1000 — the optical depth of null collisions a crossing photon would
@@ -136,6 +136,15 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
  *                    pass over the columns rotated by a per-pass random offset (stands in for the
  *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
+ *   "launch_sort"    uniform launch positions, pool kernel: -1 (default) = calls of 2^19 photons or more, 1 = all,
+ *                    0 = none take their photon IDs in the order of the launch tile (2^"sort_tile_log2" columns
+ *                    square, default 5, enlarged until there are at most 4096 tiles): a counting sort on the
+ *                    device ahead of the tracer, in batches of 2^"sort_batch_log2" IDs (default 28; 4 bytes of
+ *                    list per ID, allocated by the first rt_trace that needs it and kept), which also counts
+ *                    toa_down tile by tile. Which photon is traced when changes, no trajectory and no tally does;
+ *                    it is what keeps the reference's own launch sampling within 7 % of the stratified order on
+ *                    grids larger than the caches (the reference has no counterpart: its launch order is the
+ *                    thread index, raytracer_kernels.cu:323-331)
  *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round
  *   "chunk"          photon IDs a wave of the pool kernel takes at a time from the device-wide cursor
  *                    (power of two, default 256; halved for small jobs until every wave finds work)
@@ -174,7 +183,9 @@ int rt_prepare(rt_context* ctx);
  * library instead of the context's allocation, and the call records no timing events. Limits, refused with
  * RT_ERR_ARG / RT_ERR_STATE and a message instead of allocating: the context must use the pool kernel (option
  * "pool" > 0), photon ids end at 2^40, and the majorant tables must already exist (rt_prepare after the last
- * rt_upload_optics / option change). Every GPU holds ONE such array, shared by all contexts on it: calls of
+ * rt_upload_optics / option change). A launch sort (option "launch_sort") is done only into a list that an earlier
+ * rt_trace of at least this call's batch size has allocated; without one the IDs are taken in ascending order
+ * (slower on large grids, same results). Every GPU holds ONE such array, shared by all contexts on it: calls of
  * rt_trace_noalloc that overlap on one GPU (two streams, two threads) race on it; calls on one stream, or
  * separated by rt_synchronize, do not. rt_trace itself is unaffected and may overlap with it. */
 int rt_trace_noalloc(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t photon_count);

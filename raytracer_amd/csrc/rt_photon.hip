@@ -186,6 +186,8 @@ struct ColdBlock
     float inv_xs, inv_ys;
     uint32_t ncoarse;
     int nslab;
+    const uint32_t* sorted;       // launch sort: the launch's IDs (relative to pid_begin) in the order they are taken; or null
+    uint32_t toa_done;            // launch sort: toa_down of this launch is already counted (rt_sort_toa_kernel)
 };
 
 // The cold block through the constant address space: its contents do not change while the tracer runs (the kernel
@@ -1254,7 +1256,9 @@ rt_trace_pool_kernel(const PoolArgs a)
             uint32_t tally_word = 0xffffffffu;      // surface / domain-top tally of the fused first step
             if (go)
             {
-                const uint64_t my_pid = wave_next + (uint64_t)lane;
+                uint64_t my_pid = wave_next + (uint64_t)lane;
+                if (const uint32_t* const order = cb->sorted)       // launch sort: position in the launch -> ID
+                    my_pid = cb->pid_begin + (uint64_t)order[(uint32_t)(my_pid - cb->pid_begin)];
                 const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
                 uint32_t lk0 = key0, lk1 = key1;            // see the event stage: no hoisted, spilled round keys
                 asm volatile("" : "+s"(lk0), "+s"(lk1));
@@ -1308,6 +1312,8 @@ rt_trace_pool_kernel(const PoolArgs a)
             }
             // TOA-down tally. Stratified launch puts runs of consecutive lanes into one column: the
             // first lane of a run adds the run's length (one atomic per run instead of one per photon).
+            // (A sorted launch has counted its columns tile by tile before the tracer started.)
+            if (cb->toa_done == 0u)
             {
                 const uint32_t prev_col = (uint32_t)__shfl_up((int)toa_col, 1);
                 const bool leader = go && (lane == 0 || prev_col != toa_col);
@@ -1462,6 +1468,180 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
     }
 }
 
+// ---- Launch sort ---------------------------------------------------------------------------------------
+// With uniform launch positions (the reference's sampling, the library default) the photons a wave holds enter the
+// grid anywhere: on a grid larger than the caches every gather and every majorant lookup misses (C4: 72.9 ms per
+// 2^28 photons against 39.8 ms with the stratified launch order), and on any grid the 64 lanes of a launch round
+// add to 64 different columns of toa_down. But a photon's launch position is a function of its ID alone (first
+// Philox block), trajectories are keyed on the ID and tallies are integer sums -- so the ORDER in which a launch
+// takes its IDs is free. These kernels put the IDs of a batch in the order of their launch tile (2^tile_shift
+// columns square, tiles row by row) with a counting sort: (1) every workgroup counts the tiles of its share of
+// the IDs, (2, 3) the counts become each workgroup's first output position per tile, (4) every workgroup walks
+// its share again and writes each ID to its tile's next position (no global atomics; a workgroup's writes to one
+// tile are consecutive words), (5) toa_down of the batch is counted per column in LDS, tile by tile. Three extra
+// Philox blocks and a 4-byte write and two reads per photon: 2.1 ms per 2^28 photons. The tracer then takes
+// list[position] instead of position, and an XCD's eighth of the list is a band of tile rows. Measured per 2^28
+// photons, uniform launch: C4 72.9 -> 42.4 ms, C3 30.3 -> 28.7, C2 28.8 -> 20.9, C1 28.5 -> 17.8 (on the small grids
+// the gain is toa_down: 2^28 atomics on 16 384 addresses). Order within a tile is whatever the LDS atomics of
+// pass 4 give (it differs from run to run; the tallies cannot).
+constexpr int kSortBlock = 1024;
+constexpr uint32_t kSortMaxTiles = 4096;
+
+struct SortArgs
+{
+    uint32_t* count;              // [workgroup][tile] IDs (count pass) -> first output position (offsets pass)
+    uint32_t* tile_base;          // [tile] IDs of the tile (offsets pass) -> first output position of the tile (scan pass)
+    uint32_t* list;               // n words out: IDs relative to pid_begin, tile by tile
+    uint64_t seed, pid_begin;
+    uint32_t n, per_block, nblocks;   // IDs of the batch; IDs per workgroup; workgroups of the count and scatter passes
+    uint32_t tile_shift, ntx, ntiles;
+    int itot, jtot;
+    float xs, ys, inv_dx, inv_dy;
+    unsigned long long* toa_down; // pass 5
+    uint32_t nslices;             // pass 5: workgroups per tile
+};
+
+// launch column of photon `pid`: the launch stage's own arithmetic (uniform positions)
+__device__ __forceinline__ void launch_ij(const SortArgs& s, uint64_t pid, uint32_t key0, uint32_t key1, uint32_t& i, uint32_t& j)
+{
+    const rt::u32x4 w = rt::philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), 0u, 0u, key0, key1);
+    i = (uint32_t)rt::cell_of(s.xs * rt::u01(w.x), s.inv_dx, s.itot);
+    j = (uint32_t)rt::cell_of(s.ys * rt::u01(w.y), s.inv_dy, s.jtot);
+}
+
+__device__ __forceinline__ uint32_t launch_tile(const SortArgs& s, uint64_t pid, uint32_t key0, uint32_t key1)
+{
+    uint32_t i, j;
+    launch_ij(s, pid, key0, key1, i, j);
+    return (j >> s.tile_shift) * s.ntx + (i >> s.tile_shift);
+}
+
+// pass 1: every workgroup counts the tiles of ITS contiguous share of the IDs
+__global__ __launch_bounds__(kSortBlock) void rt_sort_count_kernel(const SortArgs s)
+{
+    __shared__ uint32_t hist[kSortMaxTiles];
+    for (uint32_t t = threadIdx.x; t < s.ntiles; t += kSortBlock)
+        hist[t] = 0u;
+    __syncthreads();
+    const uint32_t key0 = (uint32_t)s.seed, key1 = (uint32_t)(s.seed >> 32);
+    const uint64_t lo = (uint64_t)blockIdx.x * s.per_block;
+    const uint64_t hi = lo + s.per_block < (uint64_t)s.n ? lo + s.per_block : (uint64_t)s.n;
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += kSortBlock)
+        atomicAdd(&hist[launch_tile(s, s.pid_begin + r, key0, key1)], 1u);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < s.ntiles; t += kSortBlock)
+        s.count[(size_t)blockIdx.x * s.ntiles + t] = hist[t];
+}
+
+// pass 2 (one wave per tile): counts of the tile over the workgroups -> each workgroup's first position within
+// the tile, and the tile's total
+__global__ __launch_bounds__(64) void rt_sort_offsets_kernel(const SortArgs s)
+{
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    const uint32_t per = (s.nblocks + 63u) / 64u;
+    const uint32_t b0 = lane * per, b1 = b0 + per < s.nblocks ? b0 + per : s.nblocks;
+    uint32_t sum = 0u;
+    for (uint32_t b = b0; b < b1; ++b)
+        sum += s.count[(size_t)b * s.ntiles + t];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    uint32_t run = inc - sum;
+    for (uint32_t b = b0; b < b1; ++b)
+    {
+        const uint32_t c = s.count[(size_t)b * s.ntiles + t];
+        s.count[(size_t)b * s.ntiles + t] = run;
+        run += c;
+    }
+    if (lane == 63u) s.tile_base[t] = inc;
+}
+
+// pass 3 (one workgroup): exclusive scan of the tile totals, in place
+__global__ __launch_bounds__(kSortBlock) void rt_sort_scan_kernel(uint32_t* tile_base, uint32_t ntiles)
+{
+    constexpr uint32_t per = kSortMaxTiles / kSortBlock;
+    __shared__ uint32_t wave_sum[kSortBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t v[per], sum = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k)
+    {
+        const uint32_t t = threadIdx.x * per + k;
+        v[k] = t < ntiles ? tile_base[t] : 0u;
+        sum += v[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63u) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t w = 0; w < wave; ++w)
+        run += wave_sum[w];
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k)
+    {
+        const uint32_t t = threadIdx.x * per + k;
+        if (t < ntiles) tile_base[t] = run;
+        run += v[k];
+    }
+}
+
+// pass 4: every workgroup walks its share again and puts each ID at the next free position of its tile's range
+// (reserved for this workgroup by passes 2 and 3: no global atomics, and a workgroup's writes to one tile are
+// consecutive words that the L2 gathers into whole lines)
+__global__ __launch_bounds__(kSortBlock) void rt_sort_scatter_kernel(const SortArgs s)
+{
+    __shared__ uint32_t next[kSortMaxTiles];
+    for (uint32_t t = threadIdx.x; t < s.ntiles; t += kSortBlock)
+        next[t] = s.tile_base[t] + s.count[(size_t)blockIdx.x * s.ntiles + t];
+    __syncthreads();
+    const uint32_t key0 = (uint32_t)s.seed, key1 = (uint32_t)(s.seed >> 32);
+    const uint64_t lo = (uint64_t)blockIdx.x * s.per_block;
+    const uint64_t hi = lo + s.per_block < (uint64_t)s.n ? lo + s.per_block : (uint64_t)s.n;
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += kSortBlock)
+        s.list[atomicAdd(&next[launch_tile(s, s.pid_begin + r, key0, key1)], 1u)] = (uint32_t)r;
+}
+
+// pass 5 (tiles of at most 64 x 64 columns; nslices workgroups per tile): toa_down of the batch, counted per
+// column in LDS over the tile's stretch of the list -- one atomic per column and workgroup instead of one per
+// photon in the tracer, whose sorted launches put 64 different columns into the lanes of a launch round
+__global__ __launch_bounds__(kSortBlock) void rt_sort_toa_kernel(const SortArgs s)
+{
+    __shared__ uint32_t hist[kSortMaxTiles];
+    const uint32_t t = blockIdx.x / s.nslices, slice = blockIdx.x - t * s.nslices;
+    const uint32_t edge = 1u << s.tile_shift, mask = edge - 1u;
+    for (uint32_t b = threadIdx.x; b < edge * edge; b += kSortBlock)
+        hist[b] = 0u;
+    __syncthreads();
+    const uint32_t key0 = (uint32_t)s.seed, key1 = (uint32_t)(s.seed >> 32);
+    const uint32_t first = s.tile_base[t], last = t + 1u < s.ntiles ? s.tile_base[t + 1u] : s.n;
+    const uint32_t per = (last - first + s.nslices - 1u) / s.nslices;
+    const uint32_t lo = first + slice * per, hi = lo + per < last ? lo + per : last;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += kSortBlock)
+    {
+        uint32_t i, j;
+        launch_ij(s, s.pid_begin + (uint64_t)s.list[p], key0, key1, i, j);
+        atomicAdd(&hist[((j & mask) << s.tile_shift) | (i & mask)], 1u);
+    }
+    __syncthreads();
+    const uint32_t tj = t / s.ntx, ti = t - tj * s.ntx;
+    for (uint32_t b = threadIdx.x; b < edge * edge; b += kSortBlock)
+        if (hist[b] != 0u)
+        {
+            const uint32_t i = (ti << s.tile_shift) | (b & mask), j = (tj << s.tile_shift) | (b >> s.tile_shift);
+            tally_add(&s.toa_down[(size_t)j * (uint32_t)s.itot + i], (unsigned long long)hist[b]);
+        }
+}
+
 // Stores the launch block of the next pool launch and rewinds the ID cursors, in stream order.
 __global__ void rt_launch_block_kernel(ColdBlock* dst, const ColdBlock src, unsigned long long* cursor)
 {
@@ -1574,7 +1754,7 @@ struct rt_context
     bool maj_dirty = true;
     int sgx = -1, sgy = -1, sgz = -1; // supervoxel size in cells (0 = no grid, slabs only; -1 = automatic:
                                       // 3x3x2 merged by build_regions, or 8x8x4 unmerged, see build_majorants)
-    bool built_for_stratified = false; // launch mode the automatic choices were made for
+    bool built_fine = false;          // what the automatic choices were made for (wants_fine below)
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = RT_FAST_POOL;          // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
     int pool_waves_per_cu = 32;       // cap on resident waves per CU of the pool kernel
@@ -1582,6 +1762,12 @@ struct rt_context
     bool planar = false;                // 2D tracer's scattering rule (pool kernel only)
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
+    int launch_sort = -1;             // uniform launch, pool kernel: take the IDs in the order of their launch tile
+                                      // (1; 0 = never; -1 = automatic: calls of 2^19 photons or more)
+    int sort_batch_log2 = 28;         // IDs sorted (and traced) at a time: 4 bytes of list each
+    int sort_tile_log2 = 5;           // launch tile: 2^this columns square (made larger while there are > 4096 tiles)
+    uint32_t* d_sort = nullptr;       // the list, then the sort's tile tables (allocated on first use)
+    size_t sort_capacity = 0;         // IDs the list holds
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
     unsigned long long* d_events = nullptr;
@@ -1704,6 +1890,19 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
     }
 }
 
+// workgroups of the launch sort's count and scatter passes (two of 1024 threads fit a CU)
+size_t sort_blocks(const rt_context* c) { return 2u * (size_t)c->cu_count; }
+
+// packed cells that fit the Infinity Cache: uniform launch positions need no help there
+bool small_grid(const rt_context* c) { return 16ull * (unsigned long long)c->ncell <= (256ull << 20); }
+
+// Fine supervoxels with merged regions need their tables cache-resident: the stratified launch order provides that
+// on any grid, the launch sort (pool kernel, uniform launch) too, and so does a grid that fits the Infinity Cache.
+bool wants_fine(const rt_context* c)
+{
+    return c->launch_log2k >= 0 || small_grid(c) || (c->pool > 0 && c->launch_sort != 0);
+}
+
 int build_majorants(rt_context* c)
 {
     rt_slab_info& s = c->slabs;
@@ -1715,13 +1914,13 @@ int build_majorants(rt_context* c)
     // about one photon mean free path of the cumulus scenes, where the cost of crossing faces and the cost of
     // null collisions at cloud edges balance -- 3x3x2 cells on the 25 m LES grid (C4), 2x2x2 on the 50 x 50 x 25 m
     // grids (C3: 9.36 against 8.87 G photons/s with 3x3x2).
-    const bool fine = c->launch_log2k >= 0 || 16ull * (unsigned long long)c->ncell <= (256ull << 20);
+    const bool fine = wants_fine(c);
     const auto nearest = [](double target, double d) { const int n = (int)(target / d + 0.5); return n < 1 ? 1 : (n > 8 ? 8 : n); };
     const int sgx = c->sgx >= 0 ? c->sgx : (fine ? nearest(80.0, (double)c->dx) : 8),
               sgy = c->sgy >= 0 ? c->sgy : (fine ? nearest(80.0, (double)c->dy) : 8),
               sgz = c->sgz >= 0 ? c->sgz : (fine ? nearest(50.0, (double)c->dz) : 4);
     const int levels = c->levels >= 0 ? c->levels : (fine ? 5 : 0);
-    c->built_for_stratified = c->launch_log2k >= 0;
+    c->built_fine = fine;
     const int g = (s.k_lo >= 0 && sgx > 0 && sgy > 0 && sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
     s.gslab = g; s.nci = s.ncj = s.nck = 0; s.hx = s.hy = s.hz = 0.0f;
     size_t ncoarse = 0;
@@ -2020,6 +2219,27 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     }
     const bool gridded = sl.gslab >= 0;
 
+    // Launch sort (rt_sort_count_kernel): uniform launch positions, pool kernel; by default from 2^19 photons per call
+    // (below that the five small kernels cost what the order gains). The IDs go through in batches of
+    // 2^sort_batch_log2, each sorted and then traced. rt_trace_noalloc sorts only into a list that an earlier
+    // rt_trace left behind.
+    bool sorted = c->pool > 0 && c->launch_log2k < 0 &&
+                  (c->launch_sort == 1 || (c->launch_sort < 0 && count >= (1ull << 19)));
+    const uint64_t batch = sorted ? (1ull << c->sort_batch_log2) : count;
+    if (sorted && (size_t)(count < batch ? count : batch) > c->sort_capacity)
+    {
+        if (noalloc)
+            sorted = false;
+        else
+        {
+            const size_t need = (size_t)(count < batch ? count : batch);
+            if (c->d_sort) RT_HIP(hipFree(c->d_sort));
+            c->d_sort = nullptr; c->sort_capacity = 0;
+            RT_HIP(hipMalloc(&c->d_sort, sizeof(uint32_t) * (need + kSortMaxTiles * (1 + sort_blocks(c)))));
+            c->sort_capacity = need;
+        }
+    }
+
     if (!noalloc) RT_HIP(hipEventRecord(c->ev_start, c->stream));
     if (c->pool > 0)
     {
@@ -2030,10 +2250,6 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         if (per_cu > c->pool_waves_per_cu) per_cu = c->pool_waves_per_cu;
         if (per_cu < 1) per_cu = 1;
         const uint64_t pcap = (uint64_t)c->cu_count * per_cu;
-        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
-        // every resident wave still finds work
-        uint32_t chunk = (uint32_t)c->chunk;
-        while (chunk > 64u && count / chunk < 4u * pcap) chunk >>= 1;
 
         unsigned long long* cursor = c->d_events + kCursorWord;
         ColdBlock* d_cold = c->d_cold;
@@ -2047,10 +2263,8 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         }
         ColdBlock cb;
         memset(&cb, 0, sizeof(cb));
-        cb.pid_begin = pid_begin; cb.total = count;
-        cb.sub_size = (((count + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
         cb.events = c->d_events;
-        cb.chunk = chunk; cb.launch_log2k = c->launch_log2k;
+        cb.launch_log2k = c->launch_log2k;
         cb.sun_x = sl.sun[0]; cb.sun_y = sl.sun[1]; cb.sun_z = sl.sun[2];
         cb.inv_sun_x = rcp(cb.sun_x); cb.inv_sun_y = rcp(cb.sun_y); cb.inv_sun_z = rcp(cb.sun_z);
         cb.ztop = sl.zface[sl.nslab]; cb.dx = c->dx; cb.dy = c->dy; cb.albedo = c->albedo;
@@ -2074,9 +2288,52 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         a.inv_hz = gridded ? 1.0f / a.hz : 0.0f;
         a.zc0 = gridded ? sl.zface[sl.gslab] : 0.0f; a.zc1 = gridded ? sl.zface[sl.gslab + 1] : 0.0f;
 
+        SortArgs so;
+        memset(&so, 0, sizeof(so));
+        if (sorted)
+        {
+            so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;
+            so.seed = seed;
+            so.tile_shift = (uint32_t)c->sort_tile_log2;
+            const auto tiles_along = [&](int n) { return (uint32_t)((n + (1 << so.tile_shift) - 1) >> so.tile_shift); };
+            while ((uint64_t)tiles_along(c->itot) * tiles_along(c->jtot) > kSortMaxTiles) ++so.tile_shift;
+            so.ntx = tiles_along(c->itot); so.ntiles = so.ntx * tiles_along(c->jtot);
+            so.itot = c->itot; so.jtot = c->jtot;
+            so.xs = xs; so.ys = ys; so.inv_dx = a.inv_dx; so.inv_dy = a.inv_dy;
+            so.toa_down = c->d_tallies;
+            so.nslices = (uint32_t)((sort_blocks(c) + so.ntiles - 1) / so.ntiles);
+        }
+        const bool toa_pass = sorted && so.tile_shift <= 6u;      // the tile's columns fit the pass's LDS histogram
+        for (uint64_t done = 0; done < count; done += batch)
+        {
+        const uint64_t nb = count - done < batch ? count - done : batch, b0 = pid_begin + done;
+        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
+        // every resident wave still finds work
+        uint32_t chunk = (uint32_t)c->chunk;
+        while (chunk > 64u && nb / chunk < 4u * pcap) chunk >>= 1;
+        cb.pid_begin = b0; cb.total = nb;
+        cb.sub_size = (((nb + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
+        cb.chunk = chunk;
+        cb.sorted = sorted ? c->d_sort : nullptr;
+        cb.toa_done = toa_pass ? 1u : 0u;
+        if (sorted)
+        {
+            so.pid_begin = b0; so.n = (uint32_t)nb;
+            const uint64_t max_blocks = sort_blocks(c);
+            const uint64_t want = (nb + kSortBlock - 1) / kSortBlock;
+            so.nblocks = (uint32_t)(want < max_blocks ? want : max_blocks);
+            so.per_block = (uint32_t)((nb + so.nblocks - 1) / so.nblocks);
+            so.nblocks = (uint32_t)((nb + so.per_block - 1) / so.per_block);
+            hipLaunchKernelGGL(rt_sort_count_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+            hipLaunchKernelGGL(rt_sort_offsets_kernel, dim3(so.ntiles), dim3(64), 0, c->stream, so);
+            hipLaunchKernelGGL(rt_sort_scan_kernel, dim3(1), dim3(kSortBlock), 0, c->stream, so.tile_base, so.ntiles);
+            hipLaunchKernelGGL(rt_sort_scatter_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+            if (toa_pass)
+                hipLaunchKernelGGL(rt_sort_toa_kernel, dim3(so.ntiles * so.nslices), dim3(kSortBlock), 0, c->stream, so);
+        }
         // the cold block and the rewound cursors, in stream order ahead of the tracer
         hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, d_cold, cb, cursor);
-        uint64_t pblocks = (count + chunk - 1) / chunk;
+        uint64_t pblocks = (nb + chunk - 1) / chunk;
         if (pblocks > pcap) pblocks = pcap;
         const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
         const int phys = c->planar ? PHYS_PLANAR : (c->fixed_dot ? PHYS_FIXED_DOT : PHYS_COMPAT);
@@ -2117,6 +2374,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
 #endif
             default: return fail(RT_ERR_ARG, "%s: pool size %d is not in this build", who, ns);
         }
+        }   // batches
 #undef RT_LAUNCH_POOL
 #undef RT_LAUNCH_POOL_H
 #undef RT_LAUNCH_POOL_P
@@ -2268,6 +2526,7 @@ int rt_destroy(rt_context* c)
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_events) (void)hipFree(c->d_events);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_sort) (void)hipFree(c->d_sort);
     if (c->d_wire) (void)hipFree(c->d_wire);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -2333,12 +2592,29 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         if (value != 0 && value != RT_FAST_POOL && value != 64 && value != 96 && value != 128 && value != 160 && value != 192 && value != 256)
             return fail(RT_ERR_ARG, "rt_set_option: pool %lld not one of 0, 64, 96, 128, 160, 192, 256", value);
         c->pool = (int)value;
+        if (wants_fine(c) != c->built_fine) c->maj_dirty = true;      // the automatic grid depends on it
+    }
+    else if (!strcmp(name, "launch_sort"))
+    {
+        if (value < -1 || value > 1) return fail(RT_ERR_ARG, "rt_set_option: launch_sort %lld outside [-1,1]", value);
+        c->launch_sort = (int)value;
+        if (wants_fine(c) != c->built_fine) c->maj_dirty = true;
+    }
+    else if (!strcmp(name, "sort_tile_log2"))
+    {
+        if (value < 0 || value > 12) return fail(RT_ERR_ARG, "rt_set_option: sort_tile_log2 %lld outside [0,12]", value);
+        c->sort_tile_log2 = (int)value;
+    }
+    else if (!strcmp(name, "sort_batch_log2"))
+    {
+        if (value < 16 || value > 31) return fail(RT_ERR_ARG, "rt_set_option: sort_batch_log2 %lld outside [16,31]", value);
+        c->sort_batch_log2 = (int)value;
     }
     else if (!strcmp(name, "launch_log2k"))
     {
         if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
         c->launch_log2k = (int)value;
-        if ((value >= 0) != c->built_for_stratified) c->maj_dirty = true;      // the automatic grid depends on it
+        if (wants_fine(c) != c->built_fine) c->maj_dirty = true;
     }
     else if (!strcmp(name, "levels"))
     {

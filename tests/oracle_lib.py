@@ -98,10 +98,11 @@ DEFAULT_LEVELS = "auto"      # the library's defaults of options "levels" and "m
 DEFAULT_MERGE_TAU = 1.0
 
 
-def resolve_auto(scene, supergrid, levels, launch_log2k):
-    """The library's automatic choices (build_majorants in rt_photon.hip), restated: fine supervoxels with merged
-    regions when the launch is stratified or the packed cells fit the Infinity Cache, else coarse and unmerged."""
-    fine = launch_log2k >= 0 or 16 * scene.ncell <= (256 << 20)
+def resolve_auto(scene, supergrid, levels, launch_log2k, pool=128, launch_sort=-1):
+    """The library's automatic choices (wants_fine / build_majorants in rt_photon.hip), restated: fine supervoxels
+    with merged regions when the launch is stratified, the packed cells fit the Infinity Cache or the pool kernel
+    may sort its launches (its default), else coarse and unmerged."""
+    fine = launch_log2k >= 0 or 16 * scene.ncell <= (256 << 20) or (pool > 0 and launch_sort != 0)
 
     def nearest(target, d):       # whole number of cells nearest to the target length, 1..8
         return min(max(int(target / float(d) + 0.5), 1), 8)

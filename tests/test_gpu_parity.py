@@ -214,6 +214,38 @@ def test_chunked_id_distribution_does_not_change_results(rt, chunk, n):
     tr.close()
 
 
+@pytest.mark.parametrize("scene_name,n,batch_log2,tile_log2", [
+    ("tiny", 1 << 16, 28, 6), ("tiny", 200_003, 16, 0), ("tiny", 1, 28, 2), ("block_cloud", (1 << 18) + 5, 17, 4),
+    ("wide", 150_001, 16, 5), ("wide", 70_000, 28, 1), ("huge_top", 300_000, 18, 5), ("huge_top", 100_000, 28, 7)])
+def test_launch_sort_does_not_change_results(rt, scene_name, n, batch_log2, tile_log2):
+    """Option launch_sort: the pool kernel takes the IDs of a batch in the order of their launch tile (a counting
+    sort on the device ahead of the tracer, which also counts toa_down per tile). Every ID must still be traced
+    exactly once: tallies and event counts stay those of the oracle -- several batches per call, batches that the
+    sort's workgroups share unevenly, tiles of one column, a grid whose tile rows and columns are ragged (300 x 70
+    columns), one with more 32 x 32 tiles than the sort's tables hold (2200 x 2100 columns: tiles of 64 x 64), tiles
+    too large for the toa_down pass (128 x 128: the tracer counts), and a list that is reused by a smaller call."""
+    if scene_name == "wide":
+        scene = rt.scenes.cumulus(300, 70, 8, 100.0, 80.0, 60.0, n_clouds=6, seed=3, z_base=120.0, z_top=360.0)
+    elif scene_name == "huge_top":
+        scene = rt.scenes.rayleigh_column(2200, 2100, 2, 25.0, 25.0, 400.0)
+    else:
+        scene = SCENES[scene_name](rt.scenes)
+    begin = 987_654_321_000
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, launch_sort=1, sort_batch_log2=batch_log2, sort_tile_log2=tile_log2)
+    tr.trace(77, begin, n); tr.synchronize()
+    want, ev = O.photon_oracle(scene, 77, begin, n)
+    _assert_same(tr.tallies(), want)
+    assert tr.events() == ev
+    m = n // 3
+    if m:
+        tr.reset()
+        tr.trace(78, 5, m); tr.synchronize()
+        want, ev = O.photon_oracle(scene, 78, 5, m)
+        _assert_same(tr.tallies(), want)
+        assert tr.events() == ev
+    tr.close()
+
+
 @pytest.mark.parametrize("n,supergrid", [(1 << 18, (8, 8, 4)), (1 << 17, (4, 1, 2)), (50_001, None)])
 def test_planar_mode_bit_identical_to_oracle(rt, n, supergrid):
     """the 2D tracer as the jtot = 1 grid with the in-plane scattering rule (option planar)."""
@@ -563,6 +595,24 @@ def test_c4_les_grid_2p30_photons_against_reference_restatement(rt):
     assert int(np.abs(a["toa_down"].astype(np.int64) - per_col).max()) <= 8
     # toa_down is exactly even here and Poisson in the fixture: not a z-score candidate
     _check_against_fixture(a, n, "cpu_ref_c4_6e7.npz", scene, {"blocks": TWO_D[1:]})
+
+
+def test_launch_sort_at_full_size_is_identical_to_ascending_ids(rt):
+    """The launch sort at BASELINE's size: 2^28 + 12345 photons with uniform launch positions through the
+    1024x1024x128 grid in two sort batches, against the same IDs taken in ascending order (same majorant tables,
+    chosen explicitly: the automatic ones depend on the option). Every ID exactly once <=> all seven tallies
+    bit-identical; toa_down (counted by the sort's own pass) sums to the photon count."""
+    scene = rt.scenes.cumulus_c4()
+    n = (1 << 28) + 12345
+    got = []
+    for sort in (1, 0):
+        tr = rt.PhotonTracer.from_scene(scene, launch_sort=sort, sort_batch_log2=27, levels=5)
+        tr.set_supergrid(3, 3, 2)
+        tr.trace(29, 1 << 33, n); tr.synchronize()
+        got.append(tr.tallies())
+        tr.close()
+    assert int(got[0]["toa_down"].sum()) == n and rt.photon_balance(got[0]) == 0
+    _assert_same(got[0], got[1])
 
 
 @pytest.mark.parametrize("pool", [0, 128])

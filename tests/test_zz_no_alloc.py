@@ -45,8 +45,11 @@ def test_noalloc_entry_point_matches_rt_trace_twice_in_a_row(launch_log2k):
         # refused, not allocated for: the majorant tables do not exist yet
         assert lib.rt_trace_noalloc(b, 1, 0, 10) == 3 and b"rt_prepare" in lib.rt_last_error()
         assert lib.rt_prepare(b) == 0, lib.rt_last_error()
-        # first a large call, then a smaller one on the same (now used) scratch
-        for seed, begin, count in ((21, 5_000_000_000, 1 << 19), (22, 123, 40_001)):
+        # first a large call, then a smaller one on the same (now used) scratch; then one after an rt_trace on the
+        # same context has left its launch-sort list behind (uniform launch: the no-alloc call sorts into it)
+        for seed, begin, count in ((21, 5_000_000_000, 1 << 19), (22, 123, 40_001), (23, 77, (1 << 19) + 3)):
+            if seed == 23:
+                assert lib.rt_trace(b, 5, 0, 1 << 20) == 0 and lib.rt_synchronize(b) == 0, lib.rt_last_error()
             assert lib.rt_reset_tallies(a) == 0 and lib.rt_reset_tallies(b) == 0
             assert lib.rt_trace(a, seed, begin, count) == 0, lib.rt_last_error()
             assert lib.rt_trace_noalloc(b, seed, begin, count) == 0, lib.rt_last_error()

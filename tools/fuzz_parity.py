@@ -71,12 +71,17 @@ def main():
         n = int(rng.choice([1, 63, 1000, 20000, 60000]))
         pid0 = int(rng.integers(0, 1 << 39))
         seed = int(rng.integers(0, 1 << 62))
+        rng2 = np.random.default_rng(77000 + case)          # launch sort (round 2): a stream of its own, so that the
+        sort = int(rng2.choice([-1, 0, 1, 1]))              # cases of earlier sweeps keep their definitions
+        sort_tile, sort_batch = int(rng2.integers(0, 7)), int(rng2.choice([16, 28]))
         desc = dict(case=case, kind=kind, grid=(scene.itot, scene.jtot, scene.ktot), albedo=scene.albedo, zenith=scene.zenith_deg,
                     pool=pool, supergrid=sg, levels=levels, tau_milli=tau_milli, log2k=log2k, planar=planar,
-                    fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0)
+                    fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0,
+                    launch_sort=sort, sort_tile_log2=sort_tile, sort_batch_log2=sort_batch)
         tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels, merge_tau_milli=tau_milli,
                                         launch_log2k=log2k, planar=int(planar), fixed_dot=int(fixed_dot), chunk=chunk,
-                                        th_launch=thl)
+                                        th_launch=thl, launch_sort=sort, sort_tile_log2=sort_tile,
+                                        sort_batch_log2=sort_batch)
         tr.set_supergrid(*sg)
         tr.trace(seed, pid0, n)
         tr.synchronize()
