@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--photons-log2", type=int, default=None, help="photons per GPU per step (log2)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-uniform-leg", action="store_true", help="skip the extra N=1 measurement with uniform launch positions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU sample")
     ap.add_argument("--cpu-scenes", default="c1,c3",
                     help="scenes timed on the CPU besides the benchmarked one (SURVEY.md section 8d asks for C1 and C3)")
@@ -262,6 +263,26 @@ def main():
             "kernel_photons_per_s_per_gpu": n_per_gpu / (avg_kernel_ms * 1e-3),
             "scheduler": tr.sched_stats(),
         }
+        if world == 1 and launch_log2k >= 0 and not args.no_uniform_leg:
+            # beside the headline: the same step with the reference's own launch sampling (uniform positions, the
+            # library default), where the pool kernel sorts each batch's photon ids by launch tile on the device
+            tr.set_option("launch_log2k", -1)
+            tr.prepare()
+            base = (args.warmup + args.steps + 1) * n_per_gpu
+            tr.reset(); tr.trace(args.seed, base, n_per_gpu); tr.synchronize()
+            torch.cuda.synchronize()
+            tu = time.perf_counter()
+            for k in range(args.steps):
+                tr.reset(); tr.trace(args.seed, base + (k + 1) * n_per_gpu, n_per_gpu)
+            tr.synchronize()
+            torch.cuda.synchronize()
+            tu = time.perf_counter() - tu
+            tu_bal = rt.photon_balance(tr.tallies())
+            out["uniform_launch"] = {"value": n_per_gpu * args.steps / tu, "unit": "photons/s", "ms_per_step": tu / args.steps * 1e3,
+                                     "steps": args.steps, "balance": tu_bal,
+                                     "launch": "uniform random positions; photon ids sorted by launch tile on the device, inside the timed region"}
+            tr.set_option("launch_log2k", launch_log2k)
+            tr.prepare()
         prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(prof):
             try:
