@@ -5,6 +5,7 @@ python3 - <<'PY'
 s=open('/tmp/isa/mark.hip').read()
 s=s.replace('#include "../../include/rt_photon.h"','#include "/root/repo/include/rt_photon.h"')
 def mark(s, anchor, name, after=True):
+    if anchor not in s: return s
     i=s.index(anchor)
     if after: i+=len(anchor)
     return s[:i]+'\n asm volatile("; MARK_%s");\n'%name+s[i:]
