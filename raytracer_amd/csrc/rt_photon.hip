@@ -1891,7 +1891,10 @@ void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>
 }
 
 // workgroups of the launch sort's count and scatter passes (two of 1024 threads fit a CU)
-size_t sort_blocks(const rt_context* c) { return 2u * (size_t)c->cu_count; }
+#ifndef RT_SORT_BLOCKS_X2
+#define RT_SORT_BLOCKS_X2 4
+#endif
+size_t sort_blocks(const rt_context* c) { return (size_t)RT_SORT_BLOCKS_X2 * (size_t)c->cu_count / 2u; }
 
 // packed cells that fit the Infinity Cache: uniform launch positions need no help there
 bool small_grid(const rt_context* c) { return 16ull * (unsigned long long)c->ncell <= (256ull << 20); }
