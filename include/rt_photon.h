@@ -142,7 +142,7 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    device ahead of the tracer, in batches of 2^"sort_batch_log2" IDs (default 28; 4 bytes of
  *                    list per ID, allocated by the first rt_trace that needs it and kept), which also counts
  *                    toa_down tile by tile. Which photon is traced when changes, no trajectory and no tally does;
- *                    it is what keeps the reference's own launch sampling within 7 % of the stratified order on
+ *                    it is what keeps the reference's own launch sampling within 5 % of the stratified order on
  *                    grids larger than the caches (the reference has no counterpart: its launch order is the
  *                    thread index, raytracer_kernels.cu:323-331)
  *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round

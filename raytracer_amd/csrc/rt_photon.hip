@@ -1595,20 +1595,94 @@ __global__ __launch_bounds__(kSortBlock) void rt_sort_scan_kernel(uint32_t* tile
     }
 }
 
-// pass 4: every workgroup walks its share again and puts each ID at the next free position of its tile's range
-// (reserved for this workgroup by passes 2 and 3: no global atomics, and a workgroup's writes to one tile are
-// consecutive words that the L2 gathers into whole lines)
+// pass 4: every workgroup walks its share again, kSortSeg IDs at a time: the IDs of a segment are put in tile order
+// in LDS (count, scan, place) and then written out, so that consecutive lanes store consecutive words of a tile's
+// run instead of 64 unrelated words (the L2 takes a request per run, not per ID). A tile's runs follow each other at
+// the positions passes 2 and 3 reserved for this workgroup: no global atomics.
+#ifndef RT_SORT_SEG_PER
+#define RT_SORT_SEG_PER 8
+#endif
+constexpr int kSortSegPer = RT_SORT_SEG_PER, kSortSeg = kSortBlock * kSortSegPer;
+template <uint32_t MAXT>
 __global__ __launch_bounds__(kSortBlock) void rt_sort_scatter_kernel(const SortArgs s)
 {
-    __shared__ uint32_t next[kSortMaxTiles];
+    __shared__ uint32_t next[MAXT];               // the tile's next output position (of this workgroup's range)
+    __shared__ uint32_t cnt[MAXT];                // IDs of the segment per tile, then the tile's first place in the segment
+    __shared__ uint32_t sid[kSortSeg], sdst[kSortSeg];
+    __shared__ uint32_t wave_sum[kSortBlock / 64];
+    constexpr uint32_t per = MAXT / kSortBlock;   // tiles per thread in the scan
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t t = threadIdx.x; t < s.ntiles; t += kSortBlock)
         next[t] = s.tile_base[t] + s.count[(size_t)blockIdx.x * s.ntiles + t];
-    __syncthreads();
     const uint32_t key0 = (uint32_t)s.seed, key1 = (uint32_t)(s.seed >> 32);
     const uint64_t lo = (uint64_t)blockIdx.x * s.per_block;
     const uint64_t hi = lo + s.per_block < (uint64_t)s.n ? lo + s.per_block : (uint64_t)s.n;
-    for (uint64_t r = lo + threadIdx.x; r < hi; r += kSortBlock)
-        s.list[atomicAdd(&next[launch_tile(s, s.pid_begin + r, key0, key1)], 1u)] = (uint32_t)r;
+    for (uint64_t seg = lo; seg < hi; seg += kSortSeg)
+    {
+        for (uint32_t t = threadIdx.x; t < s.ntiles; t += kSortBlock)
+            cnt[t] = 0u;
+        __syncthreads();
+        uint32_t where[kSortSegPer];              // tile | rank among the segment's IDs of the tile << 12
+#pragma unroll
+        for (int k = 0; k < kSortSegPer; ++k)
+        {
+            const uint64_t r = seg + (uint64_t)k * kSortBlock + threadIdx.x;
+            where[k] = 0xffffffffu;
+            if (r < hi)
+            {
+                const uint32_t t = launch_tile(s, s.pid_begin + r, key0, key1);
+                where[k] = t | (atomicAdd(&cnt[t], 1u) << 12);
+            }
+        }
+        __syncthreads();
+        uint32_t c[per], sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k)
+        {
+            const uint32_t t = threadIdx.x * per + k;
+            c[k] = t < s.ntiles ? cnt[t] : 0u;
+            sum += c[k];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        if (lane == 63u) wave_sum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (uint32_t w = 0; w < wave; ++w)
+            run += wave_sum[w];
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k)
+        {
+            const uint32_t t = threadIdx.x * per + k;
+            if (t < s.ntiles) cnt[t] = run;
+            run += c[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortSegPer; ++k)
+            if (where[k] != 0xffffffffu)
+            {
+                const uint32_t t = where[k] & 0xfffu, rank = where[k] >> 12, place = cnt[t] + rank;
+                sid[place] = (uint32_t)(seg + (uint64_t)k * kSortBlock + threadIdx.x);
+                sdst[place] = next[t] + rank;
+            }
+        __syncthreads();
+        const uint32_t nseg = hi - seg < (uint64_t)kSortSeg ? (uint32_t)(hi - seg) : (uint32_t)kSortSeg;
+        for (uint32_t p = threadIdx.x; p < nseg; p += kSortBlock)
+            s.list[sdst[p]] = sid[p];
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k)
+        {
+            const uint32_t t = threadIdx.x * per + k;
+            if (t < s.ntiles) next[t] += c[k];
+        }
+        // (the barrier after the next segment's zeroing of cnt orders these against its readers)
+    }
 }
 
 // pass 5 (tiles of at most 64 x 64 columns; nslices workgroups per tile): toa_down of the batch, counted per
@@ -2330,7 +2404,10 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
             hipLaunchKernelGGL(rt_sort_count_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
             hipLaunchKernelGGL(rt_sort_offsets_kernel, dim3(so.ntiles), dim3(64), 0, c->stream, so);
             hipLaunchKernelGGL(rt_sort_scan_kernel, dim3(1), dim3(kSortBlock), 0, c->stream, so.tile_base, so.ntiles);
-            hipLaunchKernelGGL(rt_sort_scatter_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+            if (so.ntiles <= 1024u)
+                hipLaunchKernelGGL(rt_sort_scatter_kernel<1024u>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+            else
+                hipLaunchKernelGGL(rt_sort_scatter_kernel<kSortMaxTiles>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
             if (toa_pass)
                 hipLaunchKernelGGL(rt_sort_toa_kernel, dim3(so.ntiles * so.nslices), dim3(kSortBlock), 0, c->stream, so);
         }
