@@ -1479,9 +1479,9 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
 // the IDs, (2, 3) the counts become each workgroup's first output position per tile, (4) every workgroup walks
 // its share again and writes each ID to its tile's next position (no global atomics; a workgroup's writes to one
 // tile are consecutive words), (5) toa_down of the batch is counted per column in LDS, tile by tile. Three extra
-// Philox blocks and a 4-byte write and two reads per photon: 2.1 ms per 2^28 photons. The tracer then takes
+// Philox blocks and a 4-byte write and two reads per photon: 2.0 ms per 2^28 photons. The tracer then takes
 // list[position] instead of position, and an XCD's eighth of the list is a band of tile rows. Measured per 2^28
-// photons, uniform launch: C4 72.9 -> 42.4 ms, C3 30.3 -> 28.7, C2 28.8 -> 20.9, C1 28.5 -> 17.8 (on the small grids
+// photons, uniform launch: C4 72.9 -> 41.2 ms, C3 30.3 -> 28.7, C2 28.8 -> 20.9, C1 28.5 -> 17.8 (on the small grids
 // the gain is toa_down: 2^28 atomics on 16 384 addresses). Order within a tile is whatever the LDS atomics of
 // pass 4 give (it differs from run to run; the tallies cannot).
 constexpr int kSortBlock = 1024;
