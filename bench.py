@@ -283,6 +283,21 @@ def main():
                                      "launch": "uniform random positions; photon ids sorted by launch tile on the device, inside the timed region"}
             tr.set_option("launch_log2k", launch_log2k)
             tr.prepare()
+            uprof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_uniform.json")
+            if os.path.exists(uprof):
+                try:
+                    with open(uprof) as fh:
+                        p = json.load(fh)
+                    if p.get("photons_per_launch") == n_per_gpu:
+                        out["uniform_launch"].update({
+                            "tracer_kernel_ms": p.get("kernel_avg_ns", 0) / 1e6,
+                            "traffic": p.get("hbm_bytes_per_launch"),
+                            "fabric_reads_per_photon": p.get("fabric_reads_per_photon"),
+                            "valu_wave_insts_per_photon": p.get("valu_wave_insts_per_photon"),
+                            "counters_source": f"profiles/pmc_{args.workload}_uniform.json (rocprofv3 --pmc passes of "
+                                               "bench.py --launch-log2k -1, tracer kernel only; replayed, not measured in this run)"})
+                except Exception:
+                    pass
         prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(prof):
             try:
