@@ -61,9 +61,13 @@ def parse():
     ap.add_argument("--cpu-scenes", default="c1,c3",
                     help="scenes timed on the CPU besides the benchmarked one (SURVEY.md section 8d asks for C1 and C3)")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
-    ap.add_argument("--launch-log2k", type=int, default=5,
+    ap.add_argument("--launch-log2k", type=int, default=None,
                     help="stratified launch: 2^k consecutive photon IDs per column (-1 = uniform launch positions); "
-                         "used only when every GPU's batch is a whole number of passes over the columns")
+                         "used only when every GPU's batch is a whole number of passes over the columns. Default: 8 on "
+                         "grids beyond the caches (packed cells > 256 MiB), 5 on smaller ones, as the drivers' --launch=auto")
+    ap.add_argument("--launch-tile-log2", type=int, default=None,
+                    help="stratified launch: columns counted in tiles of 2^T columns square (0 = row by row). Default: 5 on "
+                         "grids beyond the caches whose sides are multiples of 32, else 0")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend; gloo (tallies staged through host memory) only to rehearse "
                          "the multi-rank flow on a box with one GPU")
@@ -173,10 +177,24 @@ def main():
     # Launch order: consecutive photon IDs sweep the columns of the domain top (the reference's launch is
     # a scrambled Sobol sequence over the same square), which keeps the cells a wave gathers L2-resident.
     # Every batch below is a whole number of such sweeps, so each step samples the domain top evenly.
+    # Beyond the caches (C4) the columns are counted in tiles of 32 x 32 and a column takes 2^8 IDs at a time: the
+    # photons of one tile keep its cells in the XCD's L2. Smaller grids keep rows and 2^5 (more photons per column at
+    # a time contend for the same tally words there). Same rule as the drivers' --launch=auto.
+    beyond_caches = 16 * scene.ncell > (256 << 20)
+    launch_tile_log2 = args.launch_tile_log2
+    if launch_tile_log2 is None:
+        launch_tile_log2 = 5 if beyond_caches and scene.itot % 32 == 0 and scene.jtot % 32 == 0 else 0
     launch_log2k = args.launch_log2k
-    if launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
+    if launch_log2k is None:
+        launch_log2k = 8 if beyond_caches and launch_tile_log2 > 0 else 5
+        while launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
+            launch_log2k -= 1
+    elif launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
         launch_log2k = -1
+    if launch_log2k < 0:
+        launch_tile_log2 = 0
     tr.set_option("launch_log2k", launch_log2k)
+    tr.set_option("launch_tile_log2", launch_tile_log2)
     tr.prepare()            # majorant tables now: every trace below is a pure asynchronous launch
     stream = torch.cuda.current_stream()
     # The step is raytracer_amd.distributed.ShardedTracer.step -- the code the multi-rank tests check: zero a
@@ -251,7 +269,8 @@ def main():
                                    f"albedo {scene.albedo}; step = reset + trace" + (((" + RCCL all-reduce of tallies" + (" (32-bit counts on the wire)" if sharded.wire32 else " (64-bit)")) if args.backend == "nccl" else " + gloo all-reduce staged through the host (rehearsal)") if use_dist else "")
                                    + (" (all-reduce of step k beside the trace of step k+1, double-buffered)" if overlap else ""),
                        "photons_per_gpu_per_step": n_per_gpu, "parallelism": f"photon-id sharding x{world}",
-                       "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, "
+                       "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, columns "
+                                  + (f"in tiles of {1 << launch_tile_log2} x {1 << launch_tile_log2}, " if launch_tile_log2 > 0 else "row by row, ") +
                                   f"{n_per_gpu // ((scene.itot * scene.jtot) << launch_log2k)} sweeps of the domain top per GPU per step"
                                   if launch_log2k >= 0 else "uniform random positions (the reference's sampling); photon ids taken in the order "
                                   "of their launch tile -- sorted on the device inside the timed region, kernel_ms includes the sort's passes")},
@@ -303,7 +322,8 @@ def main():
             try:
                 with open(prof) as fh:
                     p = json.load(fh)
-                if p.get("photons_per_launch") == n_per_gpu and p.get("launch_log2k", -1) == launch_log2k:
+                if (p.get("photons_per_launch") == n_per_gpu and p.get("launch_log2k", -1) == launch_log2k
+                        and p.get("launch_tile_log2", 0) == launch_tile_log2):
                     out["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
                     # counters cannot be read inside a plain run: these figures are REPLAYED from the committed
                     # rocprofv3 PMC passes of this same command, not measured by this process

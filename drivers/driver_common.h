@@ -41,10 +41,12 @@ struct Config
     // --launch=auto (default) | K | uniform: stratified launch, 2^K consecutive photon IDs per column
     // (the library's "launch_log2k"; stands in for the reference's scrambled-Sobol launch positions,
     // raytracer_kernels.cu:239-253, 331). It samples the domain top evenly only over whole passes of
-    // ncol * 2^K photons per GPU; "auto" takes the largest K <= 5 for which the photon count allows that,
-    // else uniform random positions.
+    // ncol * 2^K photons per GPU; "auto" takes the largest K <= 5 (<= 8 on grids beyond the caches, where it also
+    // counts the columns in tiles of 32 x 32: --launch-tile=T, the library's "launch_tile_log2") for which the photon
+    // count allows that, else uniform random positions (which the library sorts by launch tile on the device).
     int launch_log2k = -1;
     bool launch_auto = true;
+    int launch_tile_log2 = -1;      // stratified launch: columns counted in tiles of 2^T columns square; -1 = with auto
     // --resume: the output directory already holds the seven tally files of an earlier run and its
     // `checkpoint` file; this run adds photons [next_photon_id, next_photon_id + 2^n) to them (the restart the
     // reference prepares for by copying its tally arrays to the device, raytracer_3d.cu:89, 98-104)
@@ -171,6 +173,11 @@ inline void parse_args(int argc, char** argv, Config& c)
                 else if (val == "auto") c.launch_auto = true;
                 else { c.launch_log2k = std::stoi(val); c.launch_auto = false; }
             }
+            else if (key == "launch-tile")
+            {
+                c.launch_tile_log2 = std::stoi(val);
+                if (c.launch_tile_log2 < 0 || c.launch_tile_log2 > 8) die("--launch-tile must be 0..8 (log2 of the tile edge in columns)");
+            }
             else if (key == "zenith")
             {
                 c.zenith_deg.clear();
@@ -241,7 +248,7 @@ static const char* const kTallyNames[RT_N_TALLIES] = {
 struct Checkpoint
 {
     uint64_t seed = 0, next_photon_id = 0;
-    int itot = 0, jtot = 0, ktot = 0, launch_log2k = -1;
+    int itot = 0, jtot = 0, ktot = 0, launch_log2k = -1, launch_tile_log2 = 0;
     double zenith_deg = 0., azimuth_deg = 0.;
     float albedo = 0.f;
     bool fixed_dot = false;
@@ -254,7 +261,7 @@ inline void write_checkpoint(const std::string& dir, const Checkpoint& k)
     f << "# state of the tally files in this directory; continue with --resume\n"
       << "seed = " << k.seed << "\nnext_photon_id = " << k.next_photon_id << "\n"
       << "itot = " << k.itot << "\njtot = " << k.jtot << "\nktot = " << k.ktot << "\n"
-      << "launch_log2k = " << k.launch_log2k << "\n"
+      << "launch_log2k = " << k.launch_log2k << "\nlaunch_tile_log2 = " << k.launch_tile_log2 << "\n"
       << std::setprecision(17) << "zenith_deg = " << k.zenith_deg << "\nazimuth_deg = " << k.azimuth_deg << "\n"
       << std::setprecision(9) << "albedo = " << k.albedo << "\nfixed_dot = " << (k.fixed_dot ? 1 : 0) << "\n";
 }
@@ -280,6 +287,7 @@ inline Checkpoint read_checkpoint(const std::string& dir)
             else if (key == "jtot") k.jtot = std::stoi(val);
             else if (key == "ktot") k.ktot = std::stoi(val);
             else if (key == "launch_log2k") k.launch_log2k = std::stoi(val);
+            else if (key == "launch_tile_log2") k.launch_tile_log2 = std::stoi(val);
             else if (key == "zenith_deg") k.zenith_deg = std::stod(val);
             else if (key == "azimuth_deg") k.azimuth_deg = std::stod(val);
             else if (key == "albedo") k.albedo = std::stof(val);
@@ -315,16 +323,28 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     std::cout << "Shooting " << n_photons << " photons (" << n_photons / (64 * 512) << " per thread) " << std::endl;
 
     const size_t ncol = (size_t)c.itot * c.jtot, ncell = ncol * c.ktot;
+    // Launch order. auto: stratified by column with the largest K that gives whole passes over the columns; on a grid
+    // beyond the caches (packed cells > 256 MiB) whose sides are multiples of 32 the columns are counted in tiles of
+    // 32 x 32 and K may go up to 8 (one tile's photons keep its cells in the XCD's L2: +6 % on 1024 x 1024 x 128),
+    // smaller grids keep rows and K <= 5 (more photons per column at a time contend for the same tally words there).
+    // No K with whole passes: uniform positions, which the library sorts by launch tile on the device.
+    const bool tiles_fit = c.itot % 32 == 0 && c.jtot % 32 == 0;
+    const bool beyond_caches = 16ull * ncell > (256ull << 20);
     int launch_log2k = c.launch_log2k;
+    int launch_tile_log2 = c.launch_tile_log2 >= 0 ? c.launch_tile_log2 : (beyond_caches && tiles_fit ? 5 : 0);
     if (c.launch_auto)
     {
         launch_log2k = -1;
-        for (int k = 5; k >= 0 && launch_log2k < 0; --k)
+        for (int k = (beyond_caches && launch_tile_log2 > 0 ? 8 : 5); k >= 0 && launch_log2k < 0; --k)
             if (n_photons % ((uint64_t)c.ngpus * (ncol << k)) == 0) launch_log2k = k;
     }
     else if (launch_log2k >= 0 && n_photons % ((uint64_t)c.ngpus * (ncol << launch_log2k)) != 0)
         std::cerr << "Warning: --launch=" << launch_log2k << " covers the domain top evenly only for whole passes of "
                   << (ncol << launch_log2k) << " photons per GPU" << std::endl;
+    if (launch_log2k < 0) launch_tile_log2 = 0;
+    if (launch_tile_log2 > 0 && (c.itot % (1 << launch_tile_log2) != 0 || c.jtot % (1 << launch_tile_log2) != 0))
+        die("--launch-tile=" + std::to_string(launch_tile_log2) + " needs itot and jtot to be multiples of " +
+            std::to_string(1 << launch_tile_log2));
 
     const bool sweep_z = c.zenith_deg.size() > 1, sweep_a = c.azimuth_deg.size() > 1;
     struct Job { double zen, azi; std::string dir; Checkpoint from; };
@@ -347,13 +367,16 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
                     die("--resume: " + job.dir + "/checkpoint was written with another seed, sun position, albedo or physics option");
                 if (!c.launch_auto && k.launch_log2k != launch_log2k)
                     die("--resume: " + job.dir + " was launched with --launch=" + std::to_string(k.launch_log2k));
+                if (c.launch_tile_log2 >= 0 && k.launch_tile_log2 != c.launch_tile_log2)
+                    die("--resume: " + job.dir + " was launched with --launch-tile=" + std::to_string(k.launch_tile_log2));
             }
             jobs.push_back(job);
         }
     // a resumed run keeps the launch order of the run it continues (the passes over the columns go on)
-    if (c.resume) launch_log2k = jobs[0].from.launch_log2k;
+    if (c.resume) { launch_log2k = jobs[0].from.launch_log2k; launch_tile_log2 = jobs[0].from.launch_tile_log2; }
     for (const Job& job : jobs)
-        if (c.resume && job.from.launch_log2k != launch_log2k) die("--resume: the directories of this sweep disagree on the launch order");
+        if (c.resume && (job.from.launch_log2k != launch_log2k || job.from.launch_tile_log2 != launch_tile_log2))
+            die("--resume: the directories of this sweep disagree on the launch order");
 
     std::vector<rt_context*> ctx(c.ngpus, nullptr);
     auto t0 = std::chrono::high_resolution_clock::now();
@@ -363,6 +386,7 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
         check(rt_upload_optics(ctx[g], k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
         check(rt_set_option(ctx[g], "fixed_dot", c.fixed_dot), "rt_set_option");
         check(rt_set_option(ctx[g], "launch_log2k", launch_log2k), "rt_set_option");
+        check(rt_set_option(ctx[g], "launch_tile_log2", launch_tile_log2), "rt_set_option");
         // majorant tables on every GPU now: the launches inside the timed region below are asynchronous
         check(rt_prepare(ctx[g]), "rt_prepare");
     }
@@ -427,7 +451,7 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
         for (int t = 0; t < RT_N_TALLIES; ++t) save_binary(job.dir, kTallyNames[t], host[t].data(), host[t].size());
         Checkpoint k;
         k.seed = c.seed; k.next_photon_id = first_id + n_photons;
-        k.itot = c.itot; k.jtot = c.jtot; k.ktot = c.ktot; k.launch_log2k = launch_log2k;
+        k.itot = c.itot; k.jtot = c.jtot; k.ktot = c.ktot; k.launch_log2k = launch_log2k; k.launch_tile_log2 = launch_tile_log2;
         k.zenith_deg = job.zen; k.azimuth_deg = job.azi; k.albedo = c.albedo; k.fixed_dot = c.fixed_dot;
         write_checkpoint(job.dir, k);
     }

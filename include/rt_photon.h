@@ -136,6 +136,11 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
  *                    pass over the columns rotated by a per-pass random offset (stands in for the
  *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
+ *   "launch_tile_log2" stratified launch: T > 0 counts the columns tile by tile (tiles of 2^T x 2^T columns, row-major
+ *                    inside, tiles row by row; itot and jtot must be multiples of 2^T, else rt_trace refuses) instead of
+ *                    row by row (0, default), so that the photons in flight together share a neighbourhood in both
+ *                    directions: with T = 5 and k = 8 a tile's cells stay in the XCD's L2 while its 2^18 photons come
+ *                    through (1024 x 1024 x 128 grid: +6 % photons/s, a third of the memory traffic)
  *   "launch_sort"    uniform launch positions, pool kernel: -1 (default) = calls of 2^19 photons or more, 1 = all,
  *                    0 = none take their photon IDs in the order of the launch tile (2^"sort_tile_log2" columns
  *                    square, default 5, enlarged until there are at most 4096 tiles): a counting sort on the

@@ -221,6 +221,9 @@ typedef struct
     float merge_tau; /* a cube is merged when (majorant - mean extinction) * edge length <= merge_tau: the
                         optical depth of null collisions a photon crossing it would meet. Clear air merges
                         at any size, homogeneous cloud too; cloud edges keep their fine supervoxels. */
+    int launch_tile_log2; /* stratified launch: 0 = columns in row-major order; T > 0 = columns counted tile by tile
+                             (tiles of 2^T x 2^T columns, row-major inside, tiles row by row; itot and jtot are
+                             multiples of 2^T) */
 } oracle_scene_t;
 
 /* Majorant structure. Horizontal slabs as in the reference (below / in / above the cloud layer,
@@ -480,7 +483,7 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
     {
         /* Stratified launch (stands in for the reference's scrambled-Sobol positions,
          * raytracer_kernels.cu:239-253, 331: low-discrepancy, here keyed on the photon ID).
-         * Consecutive groups of K = 2^log2k IDs go to consecutive columns in row-major order; one
+         * Consecutive groups of K = 2^log2k IDs go to consecutive columns in row-major (or tile) order; one
          * pass over all columns takes ncol*K IDs and is rotated by a random offset drawn per
          * pass, so that any prefix of the ID sequence is unbiased; within the column the position
          * is uniform. */
@@ -492,7 +495,10 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         const uint64_t off = ((uint64_t)wp[0] * ncol) >> 32;
         uint64_t c = q + off;
         if (c >= ncol) c -= ncol;
-        const uint32_t jc = (uint32_t)(c / (uint64_t)itot), ic = (uint32_t)(c % (uint64_t)itot);
+        const int T = sc->launch_tile_log2;
+        const uint64_t tile = c >> (2 * T), within = c & ((1ull << (2 * T)) - 1ull), ntx = (uint64_t)(itot >> T);
+        const uint32_t ic = (uint32_t)(((tile % ntx) << T) | (within & ((1ull << T) - 1ull)));
+        const uint32_t jc = (uint32_t)(((tile / ntx) << T) | (within >> T));
         x = fmaf(u01(w[0]), sc->dx, (float)ic * sc->dx);
         y = fmaf(u01(w[1]), sc->dy, (float)jc * sc->dy);
     }

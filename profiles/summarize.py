@@ -36,6 +36,7 @@ if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_INSTS_VALU" in pmc:
     pmc["active_lanes_per_valu_inst"] = pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"]
     pmc["valu_wave_insts_per_photon"] = pmc["SQ_INSTS_VALU"] / photons
 pmc["launch_log2k"] = launch_log2k
+pmc["launch_tile_log2"] = int(sys.argv[5]) if len(sys.argv) > 5 else 0     # bench.py --launch-tile-log2 of the profiled run
 if "FETCH_SIZE" in pmc:
     pmc["fabric_reads_per_photon"] = pmc["FETCH_SIZE"] * 1024 / 64 / photons      # 64-byte read requests
 if "TCC_EA0_ATOMIC_sum" in pmc:

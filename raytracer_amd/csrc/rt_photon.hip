@@ -141,7 +141,8 @@ struct TraceArgs
     // row-major order, each pass over the columns rotated by a per-pass random offset
     int launch_log2k;
     float dx, dy;
-    uint32_t div_itot_mul, div_itot_shift;    // c / itot == (c * mul) >> shift for c < 2^31
+    uint32_t div_itot_mul, div_itot_shift;    // c / launch_div == (c * mul) >> shift for c < 2^31
+    uint32_t launch_div, launch_tile_log2;    // launch_div = itot, or the tiles per row of a tiled launch order
 };
 
 // Kernel arguments of the pool tracer: only what its three frequent stages (traverse, event, new direction) use
@@ -182,6 +183,7 @@ struct ColdBlock
     float sun_x, sun_y, sun_z, inv_sun_x, inv_sun_y, inv_sun_z;
     float ztop, dx, dy, albedo;
     uint32_t div_itot_mul, div_itot_shift;
+    uint32_t launch_div, launch_tile_log2;    // as TraceArgs
     float zface[4];
     float inv_xs, inv_ys;
     uint32_t ncoarse;
@@ -248,16 +250,22 @@ __device__ __forceinline__ uint32_t launch_pass_offset(uint64_t pass, uint32_t n
     return (uint32_t)(((uint64_t)w.x * ncol) >> 32);
 }
 
-// Column (i, j) of rotated column index c: row-major, division by itot through the host's magic number.
-__device__ __forceinline__ void launch_column(uint32_t div_mul, uint32_t div_shift, uint32_t itot, uint32_t c,
-                                              uint32_t& i, uint32_t& j)
+// Column (i, j) of rotated column index c. tile_log2 = 0: row-major (div = itot). tile_log2 = T > 0: the columns are
+// counted tile by tile -- tiles of 2^T x 2^T columns, row-major inside the tile, tiles row by row (div = tiles per
+// row; the grid is a whole number of tiles) -- so that the photons in flight together enter one neighbourhood in
+// BOTH directions and an XCD's L2 keeps the tile's cells while its 2^(2T+k) photons come through. The division by
+// `div` goes through the host's magic number.
+__device__ __forceinline__ void launch_column(uint32_t div_mul, uint32_t div_shift, uint32_t div, uint32_t tile_log2,
+                                              uint32_t c, uint32_t& i, uint32_t& j)
 {
-    j = (uint32_t)(((uint64_t)c * div_mul) >> div_shift);
-    i = c - j * itot;
+    const uint32_t t = c >> (2u * tile_log2), w = c & ((1u << (2u * tile_log2)) - 1u);
+    const uint32_t tj = (uint32_t)(((uint64_t)t * div_mul) >> div_shift), ti = t - tj * div;
+    i = (ti << tile_log2) | (w & ((1u << tile_log2) - 1u));
+    j = (tj << tile_log2) | (w >> tile_log2);
 }
 __device__ __forceinline__ void launch_column(const TraceArgs& a, uint32_t c, uint32_t& i, uint32_t& j)
 {
-    launch_column(a.div_itot_mul, a.div_itot_shift, (uint32_t)a.itot, c, i, j);
+    launch_column(a.div_itot_mul, a.div_itot_shift, a.launch_div, a.launch_tile_log2, c, i, j);
 }
 
 // Stratified column of one photon ID: 64-bit division per photon.
@@ -1276,7 +1284,7 @@ rt_trace_pool_kernel(const PoolArgs a)
                 {
                     const uint32_t c = launch_column_index_exact(log2k, k->ncol, my_pid, lk0, lk1);
                     uint32_t ic, jc;
-                    launch_column(cb->div_itot_mul, cb->div_itot_shift, (uint32_t)k->itot, c, ic, jc);
+                    launch_column(cb->div_itot_mul, cb->div_itot_shift, cb->launch_div, cb->launch_tile_log2, c, ic, jc);
                     const float dx = cb->dx, dy = cb->dy;
                     x = fma_(u01(w.x), dx, (float)ic * dx);
                     y = fma_(u01(w.y), dy, (float)jc * dy);
@@ -1836,6 +1844,7 @@ struct rt_context
     bool planar = false;                // 2D tracer's scattering rule (pool kernel only)
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
+    int launch_tile_log2 = 0;         // stratified launch: columns counted in tiles of 2^this columns square (0 = row-major)
     int launch_sort = -1;             // uniform launch, pool kernel: take the IDs in the order of their launch tile
                                       // (1; 0 = never; -1 = automatic: calls of 2^19 photons or more)
     int sort_batch_log2 = 28;         // IDs sorted (and traced) at a time: 4 bytes of list each
@@ -2265,6 +2274,10 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     if (c->pool > 0 && count > 0 && pid_begin + count > (1ull << 40))
         return fail(RT_ERR_ARG, "%s: the pool kernel packs photon ids into 40 bits (ids up to 2^40; option pool = 0 "
                                 "carries 64-bit ids)", who);
+    if (c->launch_log2k >= 0 && c->launch_tile_log2 > 0 &&
+        ((c->itot & ((1 << c->launch_tile_log2) - 1)) != 0 || (c->jtot & ((1 << c->launch_tile_log2) - 1)) != 0))
+        return fail(RT_ERR_ARG, "%s: option launch_tile_log2 = %d needs itot and jtot to be multiples of %d (grid %d x %d)", who,
+                    c->launch_tile_log2, 1 << c->launch_tile_log2, c->itot, c->jtot);
     if (noalloc)
     {
         if (c->pool == 0)
@@ -2287,12 +2300,14 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     const float xs = (float)c->itot * c->dx, ys = (float)c->jtot * c->dy;
     const auto rcp = [](float u) { return std::fabs(u) >= 0x1p-100f ? 1.0f / u : std::copysign(FLT_MAX, u); };   // dir_reciprocal
     // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
+    const uint32_t tile_log2 = c->launch_log2k >= 0 ? (uint32_t)c->launch_tile_log2 : 0u;
+    const uint32_t launch_div = (uint32_t)c->itot >> tile_log2;
     uint32_t div_shift, div_mul;
     {
         int l = 0;
-        while ((1u << l) < (uint32_t)c->itot) ++l;
+        while ((1u << l) < launch_div) ++l;
         div_shift = 31u + (uint32_t)l;
-        div_mul = (uint32_t)(((1ull << div_shift) / (uint64_t)c->itot) + 1ull);
+        div_mul = (uint32_t)(((1ull << div_shift) / (uint64_t)launch_div) + 1ull);
     }
     const bool gridded = sl.gslab >= 0;
 
@@ -2346,6 +2361,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         cb.inv_sun_x = rcp(cb.sun_x); cb.inv_sun_y = rcp(cb.sun_y); cb.inv_sun_z = rcp(cb.sun_z);
         cb.ztop = sl.zface[sl.nslab]; cb.dx = c->dx; cb.dy = c->dy; cb.albedo = c->albedo;
         cb.div_itot_mul = div_mul; cb.div_itot_shift = div_shift;
+        cb.launch_div = launch_div; cb.launch_tile_log2 = tile_log2;
         for (int i = 0; i < 4; ++i) cb.zface[i] = sl.zface[i];
         cb.inv_xs = 1.0f / xs; cb.inv_ys = 1.0f / ys;
         cb.ncoarse = (uint32_t)c->ncoarse; cb.nslab = sl.nslab;
@@ -2489,6 +2505,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         a.launch_log2k = c->launch_log2k;
         a.dx = c->dx; a.dy = c->dy;
         a.div_itot_mul = div_mul; a.div_itot_shift = div_shift;
+        a.launch_div = launch_div; a.launch_tile_log2 = tile_log2;
 
         uint64_t blocks = (count + kBlock - 1) / kBlock;
         const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
@@ -2673,6 +2690,11 @@ int rt_set_option(rt_context* c, const char* name, long long value)
             return fail(RT_ERR_ARG, "rt_set_option: pool %lld not one of 0, 64, 96, 128, 160, 192, 256", value);
         c->pool = (int)value;
         if (wants_fine(c) != c->built_fine) c->maj_dirty = true;      // the automatic grid depends on it
+    }
+    else if (!strcmp(name, "launch_tile_log2"))
+    {
+        if (value < 0 || value > 8) return fail(RT_ERR_ARG, "rt_set_option: launch_tile_log2 %lld outside [0,8]", value);
+        c->launch_tile_log2 = (int)value;
     }
     else if (!strcmp(name, "launch_sort"))
     {

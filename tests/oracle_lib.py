@@ -27,7 +27,8 @@ class OracleScene(C.Structure):
                 ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
                 ("zenith_rad", C.c_float), ("azimuth_rad", C.c_float), ("albedo", C.c_float),
                 ("fixed_dot", C.c_int), ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int),
-                ("launch_log2k", C.c_int), ("planar", C.c_int), ("levels", C.c_int), ("merge_tau", C.c_float)]
+                ("launch_log2k", C.c_int), ("planar", C.c_int), ("levels", C.c_int), ("merge_tau", C.c_float),
+                ("launch_tile_log2", C.c_int)]
 
 
 class OracleSlabs(C.Structure):
@@ -114,22 +115,23 @@ def resolve_auto(scene, supergrid, levels, launch_log2k, pool=128, launch_sort=-
 
 
 def oracle_scene(scene, fixed_dot=False, supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False,
-                 levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleScene:
+                 levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU, launch_tile_log2=0) -> OracleScene:
     f = np.float32
     supergrid, levels = resolve_auto(scene, supergrid, levels, launch_log2k)
     sx, sy, sz = supergrid if supergrid else (0, 0, 0)
     return OracleScene(scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
                        f(scene.zenith_deg * (math.pi / 180.0)), f(scene.azimuth_deg * (math.pi / 180.0)),
-                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar), int(levels), float(merge_tau))
+                       scene.albedo, int(fixed_dot), sx, sy, sz, int(launch_log2k), int(planar), int(levels), float(merge_tau),
+                       int(launch_tile_log2))
 
 
 def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed_dot=False,
                   supergrid=DEFAULT_SUPERGRID, launch_log2k=-1, planar=False, levels=DEFAULT_LEVELS,
-                  merge_tau=DEFAULT_MERGE_TAU):
+                  merge_tau=DEFAULT_MERGE_TAU, launch_tile_log2=0):
     """Run oracle/photon_oracle.c; returns (tallies dict, events dict). Adds into `tallies`."""
     t = tallies if tallies is not None else new_tallies(scene)
     ev = np.zeros(len(EVENT_NAMES), dtype=np.uint64)
-    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar, levels, merge_tau)
+    sc = oracle_scene(scene, fixed_dot, supergrid, launch_log2k, planar, levels, merge_tau, launch_tile_log2)
     fields = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     rc = lib().photon_oracle_trace(C.byref(sc), *[_p(a, C.c_float) for a in fields],
                                    seed, pid_begin, count, nthreads,

@@ -577,13 +577,14 @@ def test_c3_cumulus_2p28_photons_against_reference_restatement(rt):
 
 def test_c4_les_grid_2p30_photons_against_reference_restatement(rt):
     """north_star's target: >= 2^30 photons through the 1024x1024x128 LES cumulus grid (BASELINE config 4), here
-    on one GPU as four accumulating calls of 2^28 (the shards of four ranks), stratified launch. Exact
+    on one GPU as four accumulating calls of 2^28 (the shards of four ranks), stratified launch in the order the bench
+    and the drivers use on this grid (2^8 IDs per column, columns in tiles of 32 x 32: one pass per call). Exact
     balance; toa_down uniform (2^30 / 2^20 per column, up to edge rounding); against 6*10^7 photons of
     oracle/cpu_ref.cpp on the same grid (fixture cpu_ref_c4_6e7.npz): global fractions within 4 sigma, z-scores
     of the 16x16-column-block sums of the four outgoing 2-D tallies and of the per-level absorption."""
     scene = rt.scenes.cumulus_c4()
     n = 1 << 30
-    tr = rt.PhotonTracer.from_scene(scene, launch_log2k=5)
+    tr = rt.PhotonTracer.from_scene(scene, launch_log2k=8, launch_tile_log2=5)
     for r in range(4):
         tr.trace(23, r * (n // 4), n // 4)
     tr.synchronize()
@@ -621,6 +622,32 @@ def test_launch_sort_at_full_size_is_identical_to_ascending_ids(rt):
                                                 ("six_columns", 30000, 0), ("six_columns", 30000, 2),
                                                 ("block_cloud", 1 << 18, 5), ("cumulus_small", 1 << 17, 4)])
 def test_stratified_launch_bit_identical_to_oracle(rt, pool, scene_name, n, log2k):
+    _stratified_case(rt, pool, scene_name, n, log2k, 0)
+
+
+@pytest.mark.parametrize("pool", [0, 128])
+@pytest.mark.parametrize("scene_name,n,log2k,tile_log2", [("tiny", 192 * 32 * 3 + 777, 5, 2), ("tiny", 50000, 0, 1),
+                                                          ("tiny", 30000, 8, 2), ("block_cloud", 1 << 18, 3, 5),
+                                                          ("block_cloud", 200_000, 8, 7), ("cumulus_small", 1 << 17, 4, 4),
+                                                          ("cumulus_small", 100_000, 6, 3)])
+def test_tiled_stratified_launch_bit_identical_to_oracle(rt, pool, scene_name, n, log2k, tile_log2):
+    """Option launch_tile_log2: the stratified launch counts its columns tile by tile (tiles of 2^T columns square)
+    instead of row by row. Both kernels against the oracle: tiles of 2 to 128 columns, a grid that is one tile
+    (128 x 128), grids of 4 x 3 and 6 x 5 tiles, ID ranges that start in the middle of a pass."""
+    _stratified_case(rt, pool, scene_name, n, log2k, tile_log2)
+
+
+def test_tiled_launch_needs_whole_tiles(rt):
+    tr = rt.PhotonTracer.from_scene(rt.scenes.tiny(), launch_log2k=3, launch_tile_log2=3)      # 16 x 12 columns
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        tr.trace(1, 0, 1000)
+    tr.set_option("launch_log2k", -1)       # uniform launch positions: the option does not apply
+    tr.trace(1, 0, 1000); tr.synchronize()
+    assert int(tr.tallies()["toa_down"].sum()) == 1000
+    tr.close()
+
+
+def _stratified_case(rt, pool, scene_name, n, log2k, tile_log2):
     """Stratified launch (2^k consecutive photon IDs per column, rotated passes): both kernels
     against the oracle, including grids with < 128 columns (exact-division path) and ID ranges
     that start in the middle of a pass."""
@@ -629,9 +656,9 @@ def test_stratified_launch_bit_identical_to_oracle(rt, pool, scene_name, n, log2
     if scene_name == "six_columns":     # passes of 6 IDs: the 64 lanes of one launch round span many passes
         scene = rt.scenes.cumulus(3, 2, 8, 100.0, 80.0, 60.0, n_clouds=1, seed=4, z_base=120.0, z_top=360.0)
     begin = 123_456_789_012
-    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, launch_log2k=log2k)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, launch_log2k=log2k, launch_tile_log2=tile_log2)
     tr.trace(99, begin, n); tr.synchronize()
-    want, ev = O.photon_oracle(scene, 99, begin, n, launch_log2k=log2k)
+    want, ev = O.photon_oracle(scene, 99, begin, n, launch_log2k=log2k, launch_tile_log2=tile_log2)
     _assert_same(tr.tallies(), want)
     assert tr.events() == ev
     tr.close()

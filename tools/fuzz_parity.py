@@ -74,21 +74,24 @@ def main():
         rng2 = np.random.default_rng(77000 + case)          # launch sort (round 2): a stream of its own, so that the
         sort = int(rng2.choice([-1, 0, 1, 1]))              # cases of earlier sweeps keep their definitions
         sort_tile, sort_batch = int(rng2.integers(0, 7)), int(rng2.choice([16, 28]))
+        tiles = [t for t in (0, 1, 2, 3) if scene.itot % (1 << t) == 0 and scene.jtot % (1 << t) == 0]
+        ltile = int(rng2.choice(tiles)) if log2k >= 0 else 0          # tiled stratified launch order
         desc = dict(case=case, kind=kind, grid=(scene.itot, scene.jtot, scene.ktot), albedo=scene.albedo, zenith=scene.zenith_deg,
                     pool=pool, supergrid=sg, levels=levels, tau_milli=tau_milli, log2k=log2k, planar=planar,
                     fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0,
-                    launch_sort=sort, sort_tile_log2=sort_tile, sort_batch_log2=sort_batch)
+                    launch_sort=sort, sort_tile_log2=sort_tile, sort_batch_log2=sort_batch, launch_tile_log2=ltile)
         tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels, merge_tau_milli=tau_milli,
                                         launch_log2k=log2k, planar=int(planar), fixed_dot=int(fixed_dot), chunk=chunk,
                                         th_launch=thl, launch_sort=sort, sort_tile_log2=sort_tile,
-                                        sort_batch_log2=sort_batch)
+                                        sort_batch_log2=sort_batch, launch_tile_log2=ltile)
         tr.set_supergrid(*sg)
         tr.trace(seed, pid0, n)
         tr.synchronize()
         got, gev = tr.tallies(), tr.events()
         tr.close()
         want, wev = O.photon_oracle(scene, seed, pid0, n, fixed_dot=fixed_dot, supergrid=sg, launch_log2k=log2k,
-                                    planar=planar, levels=levels, merge_tau=np.float32(tau_milli / 1000.0))
+                                    planar=planar, levels=levels, merge_tau=np.float32(tau_milli / 1000.0),
+                                    launch_tile_log2=ltile)
         bad = [name for name in O.TALLY_NAMES if not np.array_equal(got[name], want[name])]
         if bad or gev != wev:
             print("MISMATCH", desc, "tallies:", bad, "events gpu/oracle:", gev, wev, flush=True)
