@@ -47,7 +47,7 @@ if "SQ_INSTS_LDS" in pmc and "SQ_LDS_BANK_CONFLICT" in pmc:
     pmc["lds_insts_per_photon"] = pmc["SQ_INSTS_LDS"] / photons
     pmc["lds_conflict_cycles_per_lds_inst"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_INSTS_LDS"]
 json.dump(pmc, open(f"{here}/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
-keys = ("photons_per_launch", "launch_log2k", "hbm_bytes_per_launch", "fabric_reads_per_photon", "atomics_per_photon",
+keys = ("photons_per_launch", "launch_log2k", "launch_tile_log2", "hbm_bytes_per_launch", "fabric_reads_per_photon", "atomics_per_photon",
         "valu_wave_insts_per_photon", "active_lanes_per_valu_inst", "salu_insts_per_photon", "lds_insts_per_photon",
         "lds_conflict_cycles_per_lds_inst", "kernel_avg_ns")
 json.dump(dict({k: pmc.get(k) for k in keys}, source=f"profiles/{tag}_pmc.json"),
