@@ -170,6 +170,43 @@ def test_stratified_launch_option_of_the_drivers(tmp_path):
             assert np.array_equal(got[name], want[name]), (arg, name)
 
 
+def test_tiled_launch_order_of_the_drivers(tmp_path):
+    """--launch-tile=T counts the columns of the stratified launch in tiles of 2^T x 2^T (the library's
+    launch_tile_log2): bit-identical to the oracle with the same order, recorded in the checkpoint, refused when the
+    grid is not a whole number of tiles. On a grid beyond the caches whose sides are multiples of 32, --launch=auto
+    chooses tiles of 32 x 32 and up to 2^8 IDs per column by itself (1024 x 1024 x 20 cells: 2^28 photons are one
+    pass; toa_down is then 256 per column up to edge rounding, the balance is exact)."""
+    sc = scenes.tiny()
+    sc.write(str(tmp_path))
+    dims = [f"--itot={sc.itot}", f"--jtot={sc.jtot}", f"--ktot={sc.ktot}", f"--dx={sc.dx}", f"--dy={sc.dy}", f"--dz={sc.dz}"]
+    r = subprocess.run([IO, "16", "--seed=5", "--launch=3", "--launch-tile=2", *dims], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want, _ = O.photon_oracle(sc, 5, 0, 1 << 16, launch_log2k=3, launch_tile_log2=2)
+    got = _read(tmp_path, sc)
+    for name in TALLY_NAMES:
+        assert np.array_equal(got[name], want[name]), name
+    ck = dict(l.split(" = ") for l in open(tmp_path / "checkpoint").read().splitlines() if " = " in l)
+    assert ck["launch_log2k"] == "3" and ck["launch_tile_log2"] == "2"
+    r = subprocess.run([IO, "16", "--launch=3", "--launch-tile=3", *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "multiples of 8" in r.stderr
+    r = subprocess.run([IO, "16", "--seed=5", "--launch=3", "--launch-tile=1", "--resume", *dims], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "--launch-tile=2" in r.stderr
+
+    big = tmp_path / "big"
+    big.mkdir()
+    sc = scenes.cumulus(1024, 1024, 20, 25.0, 25.0, 100.0, n_clouds=200, seed=11, z_base=400.0, z_top=1200.0, name="big_flat")
+    sc.write(str(big))
+    r = subprocess.run([IO, "28", "--seed=2"], cwd=big, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ck = dict(l.split(" = ") for l in open(big / "checkpoint").read().splitlines() if " = " in l)
+    assert ck["launch_log2k"] == "8" and ck["launch_tile_log2"] == "5"
+    got = _read(big, sc)
+    assert O.balance(got) == 0 and int(got["toa_down"].sum()) == 1 << 28
+    assert int(np.abs(got["toa_down"].astype(np.int64) - 256).max()) <= 8
+
+
 def test_io_driver_reads_the_sidecar_header(tmp_path):
     """f3: with grid.hdr beside the data files the driver needs no --itot/--dx options; float64 files work."""
     sc = scenes.tiny()
