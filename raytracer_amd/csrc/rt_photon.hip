@@ -2299,7 +2299,8 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     const rt_slab_info& sl = c->slabs;
     const float xs = (float)c->itot * c->dx, ys = (float)c->jtot * c->dy;
     const auto rcp = [](float u) { return std::fabs(u) >= 0x1p-100f ? 1.0f / u : std::copysign(FLT_MAX, u); };   // dir_reciprocal
-    // magic number for c / itot, exact for c < 2^31 (Granlund-Montgomery, N = 31)
+    // stratified launch: the divisor of launch_column (itot, or the tiles per row of a tiled order) and its magic
+    // number, exact for c < 2^31 (Granlund-Montgomery, N = 31)
     const uint32_t tile_log2 = c->launch_log2k >= 0 ? (uint32_t)c->launch_tile_log2 : 0u;
     const uint32_t launch_div = (uint32_t)c->itot >> tile_log2;
     uint32_t div_shift, div_mul;
@@ -2399,77 +2400,77 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         const bool toa_pass = sorted && so.tile_shift <= 6u;      // the tile's columns fit the pass's LDS histogram
         for (uint64_t done = 0; done < count; done += batch)
         {
-        const uint64_t nb = count - done < batch ? count - done : batch, b0 = pid_begin + done;
-        // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
-        // every resident wave still finds work
-        uint32_t chunk = (uint32_t)c->chunk;
-        while (chunk > 64u && nb / chunk < 4u * pcap) chunk >>= 1;
-        cb.pid_begin = b0; cb.total = nb;
-        cb.sub_size = (((nb + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
-        cb.chunk = chunk;
-        cb.sorted = sorted ? c->d_sort : nullptr;
-        cb.toa_done = toa_pass ? 1u : 0u;
-        if (sorted)
-        {
-            so.pid_begin = b0; so.n = (uint32_t)nb;
-            const uint64_t max_blocks = sort_blocks(c);
-            const uint64_t want = (nb + kSortBlock - 1) / kSortBlock;
-            so.nblocks = (uint32_t)(want < max_blocks ? want : max_blocks);
-            so.per_block = (uint32_t)((nb + so.nblocks - 1) / so.nblocks);
-            so.nblocks = (uint32_t)((nb + so.per_block - 1) / so.per_block);
-            hipLaunchKernelGGL(rt_sort_count_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
-            hipLaunchKernelGGL(rt_sort_offsets_kernel, dim3(so.ntiles), dim3(64), 0, c->stream, so);
-            hipLaunchKernelGGL(rt_sort_scan_kernel, dim3(1), dim3(kSortBlock), 0, c->stream, so.tile_base, so.ntiles);
-            if (so.ntiles <= 1024u)
-                hipLaunchKernelGGL(rt_sort_scatter_kernel<1024u>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
-            else
-                hipLaunchKernelGGL(rt_sort_scatter_kernel<kSortMaxTiles>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
-            if (toa_pass)
-                hipLaunchKernelGGL(rt_sort_toa_kernel, dim3(so.ntiles * so.nslices), dim3(kSortBlock), 0, c->stream, so);
-        }
-        // the cold block and the rewound cursors, in stream order ahead of the tracer
-        hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, d_cold, cb, cursor);
-        uint64_t pblocks = (nb + chunk - 1) / chunk;
-        if (pblocks > pcap) pblocks = pcap;
-        const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
-        const int phys = c->planar ? PHYS_PLANAR : (c->fixed_dot ? PHYS_FIXED_DOT : PHYS_COMPAT);
-        // NS = 128 is the tuned default and comes with and without the event counters; the other pool sizes exist
-        // for experiments and tests and always count
+            const uint64_t nb = count - done < batch ? count - done : batch, b0 = pid_begin + done;
+            // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
+            // every resident wave still finds work
+            uint32_t chunk = (uint32_t)c->chunk;
+            while (chunk > 64u && nb / chunk < 4u * pcap) chunk >>= 1;
+            cb.pid_begin = b0; cb.total = nb;
+            cb.sub_size = (((nb + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
+            cb.chunk = chunk;
+            cb.sorted = sorted ? c->d_sort : nullptr;
+            cb.toa_done = toa_pass ? 1u : 0u;
+            if (sorted)
+            {
+                so.pid_begin = b0; so.n = (uint32_t)nb;
+                const uint64_t max_blocks = sort_blocks(c);
+                const uint64_t want = (nb + kSortBlock - 1) / kSortBlock;
+                so.nblocks = (uint32_t)(want < max_blocks ? want : max_blocks);
+                so.per_block = (uint32_t)((nb + so.nblocks - 1) / so.nblocks);
+                so.nblocks = (uint32_t)((nb + so.per_block - 1) / so.per_block);
+                hipLaunchKernelGGL(rt_sort_count_kernel, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+                hipLaunchKernelGGL(rt_sort_offsets_kernel, dim3(so.ntiles), dim3(64), 0, c->stream, so);
+                hipLaunchKernelGGL(rt_sort_scan_kernel, dim3(1), dim3(kSortBlock), 0, c->stream, so.tile_base, so.ntiles);
+                if (so.ntiles <= 1024u)
+                    hipLaunchKernelGGL(rt_sort_scatter_kernel<1024u>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+                else
+                    hipLaunchKernelGGL(rt_sort_scatter_kernel<kSortMaxTiles>, dim3(so.nblocks), dim3(kSortBlock), 0, c->stream, so);
+                if (toa_pass)
+                    hipLaunchKernelGGL(rt_sort_toa_kernel, dim3(so.ntiles * so.nslices), dim3(kSortBlock), 0, c->stream, so);
+            }
+            // the cold block and the rewound cursors, in stream order ahead of the tracer
+            hipLaunchKernelGGL(rt_launch_block_kernel, dim3(1), dim3(64), 0, c->stream, d_cold, cb, cursor);
+            uint64_t pblocks = (nb + chunk - 1) / chunk;
+            if (pblocks > pcap) pblocks = pcap;
+            const dim3 grid((unsigned)pblocks), pblock(kPoolBlock);
+            const int phys = c->planar ? PHYS_PLANAR : (c->fixed_dot ? PHYS_FIXED_DOT : PHYS_COMPAT);
+            // NS = 128 is the tuned default and comes with and without the event counters; the other pool sizes exist
+            // for experiments and tests and always count
 #define RT_LAUNCH_POOL_PS(P, S, NS, H) hipLaunchKernelGGL((rt_trace_pool_kernel<P, S, NS, H>), grid, pblock, 0, c->stream, a)
 #define RT_LAUNCH_POOL_P(P, NS, H)                                                                             \
-        do {                                                                                                   \
-            if (NS != RT_FAST_POOL || c->stats) RT_LAUNCH_POOL_PS(P, true, NS, H);                             \
-            else RT_LAUNCH_POOL_PS(P, (NS != RT_FAST_POOL), NS, H);                                            \
-        } while (0)
+            do {                                                                                                   \
+                if (NS != RT_FAST_POOL || c->stats) RT_LAUNCH_POOL_PS(P, true, NS, H);                             \
+                else RT_LAUNCH_POOL_PS(P, (NS != RT_FAST_POOL), NS, H);                                            \
+            } while (0)
 #define RT_LAUNCH_POOL_H(NS, H)                                                                                \
-        do {                                                                                                   \
-            if (phys == PHYS_PLANAR) RT_LAUNCH_POOL_P(PHYS_PLANAR, NS, H);                                     \
-            else if (phys == PHYS_FIXED_DOT) RT_LAUNCH_POOL_P(PHYS_FIXED_DOT, NS, H);                          \
-            else RT_LAUNCH_POOL_P(PHYS_COMPAT, NS, H);                                                         \
-        } while (0)
+            do {                                                                                                   \
+                if (phys == PHYS_PLANAR) RT_LAUNCH_POOL_P(PHYS_PLANAR, NS, H);                                     \
+                else if (phys == PHYS_FIXED_DOT) RT_LAUNCH_POOL_P(PHYS_FIXED_DOT, NS, H);                          \
+                else RT_LAUNCH_POOL_P(PHYS_COMPAT, NS, H);                                                         \
+            } while (0)
 #define RT_LAUNCH_POOL(NS)                                                                                     \
-        do {                                                                                                   \
-            if (c->hier) RT_LAUNCH_POOL_H(NS, true); else RT_LAUNCH_POOL_H(NS, false);                         \
-        } while (0)
-        switch (ns)
-        {
-            case RT_FAST_POOL: RT_LAUNCH_POOL(RT_FAST_POOL); break;
+            do {                                                                                                   \
+                if (c->hier) RT_LAUNCH_POOL_H(NS, true); else RT_LAUNCH_POOL_H(NS, false);                         \
+            } while (0)
+            switch (ns)
+            {
+                case RT_FAST_POOL: RT_LAUNCH_POOL(RT_FAST_POOL); break;
 #ifndef RT_ONLY_DEFAULT_POOL
 #if RT_FAST_POOL != 64
-            case 64: RT_LAUNCH_POOL(64); break;
+                case 64: RT_LAUNCH_POOL(64); break;
 #endif
 #if RT_FAST_POOL != 96
-            case 96: RT_LAUNCH_POOL(96); break;
+                case 96: RT_LAUNCH_POOL(96); break;
 #endif
 #if RT_FAST_POOL != 128
-            case 128: RT_LAUNCH_POOL(128); break;
+                case 128: RT_LAUNCH_POOL(128); break;
 #endif
-            case 160: RT_LAUNCH_POOL(160); break;
-            case 192: RT_LAUNCH_POOL(192); break;
-            case 256: RT_LAUNCH_POOL(256); break;
+                case 160: RT_LAUNCH_POOL(160); break;
+                case 192: RT_LAUNCH_POOL(192); break;
+                case 256: RT_LAUNCH_POOL(256); break;
 #endif
-            default: return fail(RT_ERR_ARG, "%s: pool size %d is not in this build", who, ns);
-        }
+                default: return fail(RT_ERR_ARG, "%s: pool size %d is not in this build", who, ns);
+            }
         }   // batches
 #undef RT_LAUNCH_POOL
 #undef RT_LAUNCH_POOL_H
