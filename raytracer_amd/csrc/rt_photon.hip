@@ -681,7 +681,9 @@ rt_trace_kernel(const TraceArgs a)
 // 2^28 photons is about 2 * 10^4 rounds per wave), so the guard cannot fire on one. Non-finite positions are
 // caught in the step itself, at once.
 // (state >> 2 is the stage that serves it: 0 traverse, 1 event, 3 launch, 4 slab; class 2 was round 1's new-direction stage)
-enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_LAUNCH = 12, PS_SLAB = 16, PS_DONE = 20 };
+// PS_LAUNCH_TALLY: a free slot whose last photon was absorbed in the air; word 0 of its record holds the tally word
+// that the next launch round adds to (see the event stage)
+enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_LAUNCH = 12, PS_LAUNCH_TALLY = 13, PS_SLAB = 16, PS_DONE = 20 };
 enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
 constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
@@ -1149,11 +1151,15 @@ rt_trace_pool_kernel(const PoolArgs a)
                         }
                         else
                         {
-                            // absorption, raytracer_kernels.cu:551-566
+                            // absorption, raytracer_kernels.cu:551-566. The atomic itself is left to the launch round
+                            // that refills this slot: issued here, in 36 M event rounds per 2^28 photons with six
+                            // absorbing lanes each, every round's next wait for a gather (an L2 hit since the tiled
+                            // launch order) also waits for a read-modify-write in HBM (2.2 of 37.6 ms on C4); a launch
+                            // round (6.5 M) adds for all the slots it refills at once.
                             if (STATS) ++ev_abs;
                             const bool diffuse = (cks >> 24) & 1u;
-                            tally_add(&k->tallies[5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell]);
-                            ns = PS_LAUNCH;
+                            RW(0) = 5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell;
+                            ns = PS_LAUNCH_TALLY;
                             alive = false;
                         }
                     }
@@ -1256,6 +1262,19 @@ rt_trace_pool_kernel(const PoolArgs a)
                     wave_next = cb->pid_begin + c0;
                     wave_left = sub_hi - c0 < (uint64_t)chunk ? (uint32_t)(sub_hi - c0) : chunk;
                 }
+            }
+            // absorption tallies the event stage left with the slots (PS_LAUNCH_TALLY): the states live with the owners
+            // (adding at the end of the stage instead, behind its loads and its returning cursor atomic: no difference)
+            {
+                uint32_t st = 0u;
+#pragma unroll
+                for (int h = 0; h < kHalves; ++h)
+                {
+                    const uint32_t v = BPERM(slot & 63u, stv[h]);
+                    if ((slot >> 6) == (uint32_t)h) st = v;
+                }
+                if (active && st == PS_LAUNCH_TALLY)
+                    tally_add(&k->tallies[RW(0)]);
             }
             const bool go = active && (uint32_t)lane < wave_left;
             if (active && ranges_dry < (uint32_t)kXcds)
