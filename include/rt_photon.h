@@ -144,7 +144,7 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *   "launch_sort"    uniform launch positions, pool kernel: -1 (default) = calls of 2^19 photons or more, 1 = all,
  *                    0 = none take their photon IDs in the order of the launch tile (2^"sort_tile_log2" columns
  *                    square, default 5, enlarged until there are at most 4096 tiles): a counting sort on the
- *                    device ahead of the tracer, in batches of 2^"sort_batch_log2" IDs (default 28; 4 bytes of
+ *                    device ahead of the tracer, in batches of 2^"sort_batch_log2" IDs (default 30; 4 bytes of
  *                    list per ID, allocated by the first rt_trace that needs it and kept), which also counts
  *                    toa_down tile by tile. Which photon is traced when changes, no trajectory and no tally does;
  *                    it is what keeps the reference's own launch sampling within 5 % of the stratified order on
