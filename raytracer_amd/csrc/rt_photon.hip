@@ -1106,17 +1106,15 @@ rt_trace_pool_kernel(const PoolArgs a)
                 {
                     // the traverse and slab stages leave 1/M of the region in the tau slot (tau itself is
                     // dead until the draw below); a photon on the surface has its column from (x, y)
+                    // (no branch around the gather: a photon on the surface reads the cell above it and ignores it, and
+                    // the stage's scalar argument loads are issued in one batch instead of one per basic block)
                     const int i = cell_of(g0.x, k->inv_dx, k->itot), j = cell_of(g0.y, k->inv_dy, k->jtot);
+                    const uint32_t kz = (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot);
+                    cr = k->cells[brick_index((uint32_t)i, (uint32_t)j, kz, k->nbi, k->nbij)];
                     cell = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
-                    if (!on_surface)
-                    {
-                        inv_m = g0.w;
-                        const uint32_t kz = (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot);
-                        cr = k->cells[brick_index((uint32_t)i, (uint32_t)j, kz, k->nbi, k->nbij)];
-                        cell += kz * k->ncol;           // the [k][j][i] index, for the absorption tally
-                    }
-                    if (slab == a.gslab)
-                        mm_pre = a.maj[(uint32_t)((ck * a.ncj + cj) * a.nci + ci)];
+                    inv_m = g0.w;
+                    cell += (on_surface ? 0u : kz) * k->ncol;   // the [k][j][i] index, for the absorption tally
+                    mm_pre = a.maj[slab == a.gslab ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : 0u];
                 }
                 __builtin_amdgcn_s_setprio(0);
                 const float kt = cr.x;
