@@ -724,13 +724,11 @@ constexpr int kPoolBlock = 64;
 // outside the grid: the clear-air slabs, the domain top and the surface. 1/M is finite in the tables
 // (majorant_reciprocal), so tau * (1/M) is a number whatever the region holds.
 #define RT_TRAVERSE_STEP(IX, IY, IZ, MM) \
-                if (__builtin_expect(!(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask), 0)) \
                 { \
-                    tally_add(&cold_of(a)->events[RT_EV_ABORT]); \
-                    ns = PS_LAUNCH; \
-                } \
-                else \
-                { \
+                    /* the step guard (a position that is not a number, or a photon of age 31 in a tick round): the step */ \
+                    /* is taken regardless -- its indices stay inside the tables whatever the position holds -- and */ \
+                    /* the photon is retired after it: no else-branch around the hot code */ \
+                    const bool bad = !(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask); \
                     age += age_inc; \
                     if (STATS) ++ev_step; \
                     const float2 mm = (MM); \
@@ -786,6 +784,11 @@ constexpr int kPoolBlock = 64;
                     slab += leave ? (up ? 1 : -1) : 0; \
                     ns = hit ? (leave ? PS_SLAB : PS_TRAVERSE) : PS_COLLIDE; \
                     if (STATS) ev_trans += hit ? 1u : 0u; \
+                    if (__builtin_expect(bad, 0)) \
+                    { \
+                        tally_add(&cold_of(a)->events[RT_EV_ABORT]); \
+                        ns = PS_LAUNCH; \
+                    } \
                 }
 
 // The new direction of a photon that scatters (phase function + rotation, raytracer_kernels.cu:520-548) or is
@@ -822,16 +825,11 @@ constexpr int kPoolBlock = 64;
                     { \
                         const float mu = (FROM_CLOUD) ? henyey_mu((ASY), (UMU)) : rayleigh_mu((UMU)); \
                         const float sn = rt_sqrt(__builtin_fmaxf(fma_(-mu, mu, 1.0f) + RT_EPS, 0.0f)); \
-                        float ax = 0.0f, ay = 0.0f, az = 0.0f; \
+                        /* the axis of the smallest direction component (raytracer_kernels.cu:523-533), as selects */ \
                         const float fx = __builtin_fabsf(ux), fy = __builtin_fabsf(uy), fz = __builtin_fabsf(uz); \
-                        if (fx < fy) \
-                        { \
-                            if (fx < fz) ax = 1.0f; else az = 1.0f; \
-                        } \
-                        else \
-                        { \
-                            if (fy < fz) ay = 1.0f; else az = 1.0f; \
-                        } \
+                        const bool x_lt_y = fx < fy; \
+                        const bool pick_x = x_lt_y && fx < fz, pick_y = !x_lt_y && fy < fz; \
+                        const float ax = pick_x ? 1.0f : 0.0f, ay = pick_y ? 1.0f : 0.0f, az = (pick_x || pick_y) ? 0.0f : 1.0f; \
                         /* dot(t1, dir): the reference's third term is t1.z*t1.z (raytracer_kernels.cu:73) */ \
                         const float proj = FIXED_DOT ? fma_(az, uz, fma_(ay, uy, ax * ux)) \
                                                      : fma_(az, az, fma_(ay, uy, ax * ux)); \
@@ -1129,53 +1127,39 @@ rt_trace_pool_kernel(const PoolArgs a)
                 float tau_new = free_path_tau(u01(w.y));
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
 
-                bool alive = true, turn = false, reflect = false, from_cloud = false;
-                float u_mu = 0.0f, u_phi = 0.0f;
-                if (!on_surface)
+                // Collision classification (raytracer_kernels.cu:507-518) or the surface's albedo test (:463-486), as
+                // predicates: the half-dozen small divergent blocks this was cost more in exec-mask bookkeeping on the
+                // CU's one scalar unit than their arithmetic.
+                const float rr = u01(w.x);
+                const float p_real = kt * inv_m;
+                const float s_scat = cr.y * p_real;
+                const bool real = !on_surface && rr < p_real;
+                const bool scat = real && rr <= s_scat;
+                const bool absorbed = real && !scat;                    // absorption, raytracer_kernels.cu:551-566
+                const bool from_cloud = rr * kt < s_scat * cr.w;        // r/s < k_cloud/k_tot
+                const bool reflect = on_surface && rr <= cold_of(a)->albedo;
+                const bool turn = scat || reflect;
+                const bool alive = !(absorbed || (on_surface && !reflect));
+                const float u_mu = u01(on_surface ? w.y : w.z), u_phi = u01(on_surface ? w.z : w.w);
+                if (STATS)
                 {
-                    // collision classification, raytracer_kernels.cu:507-518
-                    if (STATS) ++ev_coll;
-                    const float rr = u01(w.x);
-                    const float p_real = kt * inv_m;
-                    if (rr < p_real)
-                    {
-                        if (STATS) ++ev_real;
-                        const float s_scat = cr.y * p_real;
-                        if (rr <= s_scat)
-                        {
-                            from_cloud = rr * kt < s_scat * cr.w;   // r/s < k_cloud/k_tot
-                            if (STATS) { ++ev_scat; if (from_cloud) ++ev_cscat; }
-                            turn = true; u_mu = u01(w.z); u_phi = u01(w.w);
-                        }
-                        else
-                        {
-                            // absorption, raytracer_kernels.cu:551-566. The atomic itself is left to the launch round
-                            // that refills this slot: issued here, in 36 M event rounds per 2^28 photons with six
-                            // absorbing lanes each, every round's next wait for a gather (an L2 hit since the tiled
-                            // launch order) also waits for a read-modify-write in HBM (2.2 of 37.6 ms on C4); a launch
-                            // round (6.5 M) adds for all the slots it refills at once.
-                            if (STATS) ++ev_abs;
-                            const bool diffuse = (cks >> 24) & 1u;
-                            RW(0) = 5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell;
-                            ns = PS_LAUNCH_TALLY;
-                            alive = false;
-                        }
-                    }
+                    if (!on_surface) ++ev_coll;
+                    if (real) ++ev_real;
+                    if (scat) { ++ev_scat; if (from_cloud) ++ev_cscat; }
+                    if (absorbed) ++ev_abs;
                 }
-                else
+                if (absorbed)
                 {
-                    // surface: absorb or reflect, raytracer_kernels.cu:463-486
-                    if (u01(w.x) <= cold_of(a)->albedo)
-                    {
-                        tally_add(&k->tallies[4u * k->ncol + cell]);
-                        turn = reflect = true; u_mu = u01(w.y); u_phi = u01(w.z);
-                    }
-                    else
-                    {
-                        ns = PS_LAUNCH;
-                        alive = false;
-                    }
+                    // The atomic itself is left to the launch round that refills this slot: issued here, in 36 M event
+                    // rounds per 2^28 photons with six absorbing lanes each, every round's next wait for a gather (an
+                    // L2 hit since the tiled launch order) also waits for a read-modify-write in HBM (2.2 of 37.6 ms on
+                    // C4); a launch round (6.5 M) adds for all the slots it refills at once.
+                    const bool diffuse = (cks >> 24) & 1u;
+                    RW(0) = 5u * k->ncol + (diffuse ? k->ncol * (uint32_t)k->ktot : 0u) + cell;
                 }
+                if (reflect)
+                    tally_add(&k->tallies[4u * k->ncol + cell]);
+                ns = absorbed ? PS_LAUNCH_TALLY : PS_LAUNCH;            // (a photon that lives on gets its state below)
                 if (alive)
                 {
                     float x = g0.x, y = g0.y, z = g0.z;
