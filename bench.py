@@ -180,15 +180,13 @@ def main():
     # Beyond the caches (C4) the columns are counted in tiles of 32 x 32 and a column takes 2^8 IDs at a time: the
     # photons of one tile keep its cells in the XCD's L2. Smaller grids keep rows and 2^5 (more photons per column at
     # a time contend for the same tally words there). Same rule as the drivers' --launch=auto.
-    beyond_caches = 16 * scene.ncell > (256 << 20)
-    launch_tile_log2 = args.launch_tile_log2
-    if launch_tile_log2 is None:
-        launch_tile_log2 = 5 if beyond_caches and scene.itot % 32 == 0 and scene.jtot % 32 == 0 else 0
+    auto_k, auto_tile = rt.choose_launch_order(scene.itot, scene.jtot, scene.ktot, n_per_gpu)
+    launch_tile_log2 = args.launch_tile_log2 if args.launch_tile_log2 is not None else auto_tile
     launch_log2k = args.launch_log2k
     if launch_log2k is None:
-        launch_log2k = 8 if beyond_caches and launch_tile_log2 > 0 else 5
-        while launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
-            launch_log2k -= 1
+        launch_log2k = auto_k
+        if launch_tile_log2 == 0 and launch_log2k > 5:      # tiles switched off by hand: rows take k <= 5
+            launch_log2k = 5
     elif launch_log2k >= 0 and n_per_gpu % ((scene.itot * scene.jtot) << launch_log2k) != 0:
         launch_log2k = -1
     if launch_log2k < 0:

@@ -277,6 +277,24 @@ def allreduce(tracers):
     _check(lib.rt_allreduce(arr, len(tracers)))
 
 
+def choose_launch_order(itot, jtot, ktot, photons_per_call, ngpus=1):
+    """The launch order the drivers' --launch=auto and bench.py use: (launch_log2k, launch_tile_log2).
+
+    Stratified by column with the largest k that gives every GPU whole passes over the columns (ncol * 2^k photon
+    IDs each). On a grid beyond the caches (16 bytes of packed cell per cell > 256 MiB) whose sides are multiples
+    of 32 the columns are counted in tiles of 32 x 32 and k may go up to 8: a tile's 2^(10+k) photons keep its
+    cells in one XCD's L2 (1024 x 1024 x 128: a third of the memory traffic, +6 % photons/s). Smaller grids keep
+    rows and k <= 5 (more photons per column at a time contend for the same tally words there). No k with whole
+    passes: (-1, 0), uniform launch positions, which the library sorts by launch tile on the device."""
+    ncol = itot * jtot
+    beyond_caches = 16 * ncol * ktot > (256 << 20)
+    tile = 5 if beyond_caches and itot % 32 == 0 and jtot % 32 == 0 else 0
+    for k in range(8 if tile else 5, -1, -1):
+        if photons_per_call % (ngpus * (ncol << k)) == 0:
+            return k, tile
+    return -1, 0
+
+
 def split_tally_words(words, itot, jtot, ktot):
     """Concatenated tally buffer (host array of nwords) -> dict of the seven arrays."""
     ncol, ncell = itot * jtot, itot * jtot * ktot
