@@ -177,7 +177,9 @@ int rt_trace(rt_context* ctx, uint64_t seed, uint64_t photon_id_begin, uint64_t 
 /* Runs everything rt_trace would otherwise do on its first call after rt_upload_optics or an option change:
  * the device pre-pass over supervoxels and the host-side merge into majorant regions (allocates the tables).
  * Calling it ahead of a timed or latency-critical section makes every rt_trace in it a pure asynchronous
- * launch. Part of what cloud_mask_kernel's launch stands for (raytracer_3d.cu:116-130). */
+ * launch -- except the first one that sorts its launches (option "launch_sort": uniform launch positions, 2^19
+ * photons or more), which allocates the list for its batch size; a warm-up call of the largest size does that too.
+ * Part of what cloud_mask_kernel's launch stands for (raytracer_3d.cu:116-130). */
 int rt_prepare(rt_context* ctx);
 
 /* rt_trace for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
