@@ -111,6 +111,32 @@ def cpu_sample(scene, seconds, threads):
     return {"value": traced / dt, "unit": "photons/s", "cores": threads, "photons": traced, "seconds": dt}
 
 
+def reference_binary_sample(threads, arg):
+    """The COMPILED REFERENCE itself (oracle/_ref/raytracer_3d_ref, built from /root/reference/src/raytracer_3d.cpp by
+    oracle/Makefile; its only scene is the block cloud = workload c1) on this host: `arg` x 10^5 photons, its own
+    'Duration' line, photons counted from the toa_down file it writes. None when the binary is not there."""
+    import re
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "raytracer_3d_ref")
+    if not os.access(exe, os.X_OK):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            r = subprocess.run([exe, str(arg)], cwd=d, env=dict(os.environ, OMP_NUM_THREADS=str(threads)),
+                               capture_output=True, text=True, timeout=180)
+            m = re.search(r"Duration:\s*([0-9.eE+-]+)", r.stdout)
+            if r.returncode != 0 or not m:
+                return None
+            traced = int(np.fromfile(os.path.join(d, "toa_down.bin"), dtype=np.uint64).sum())
+        dur = float(m.group(1))
+        return {"value": traced / dur, "unit": "photons/s", "cores": threads, "photons": traced, "seconds": dur,
+                "kind": "reference", "command": f"oracle/_ref/raytracer_3d_ref {arg}"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene, seconds, workload, extra_scenes):
     """the bit-pinned restatement of raytracer_3d.cpp on all of this GPU's share of the host
     cores and on one thread, CPU model named; the headline entry is the all-cores figure on the benchmarked scene."""
@@ -123,12 +149,24 @@ def cpu_baseline(scene, seconds, workload, extra_scenes):
                      f"(double, xoroshiro128+, global majorant; bit-pinned to raytracer_3d.cpp) in {full['seconds']:.2f} s",
            "cpu_model": cpu_model(),
            "one_thread": {k: one[k] for k in ("value", "unit", "cores", "photons", "seconds")}}
+    def reference_binary():      # the compiled reference runs its own scene only: the block cloud (c1)
+        ref = {"all_cores": reference_binary_sample(cores, 300), "one_thread": reference_binary_sample(1, 20)}
+        return ref if ref["all_cores"] and ref["one_thread"] else None
+
+    if workload == "c1":
+        ref = reference_binary()
+        if ref:
+            out["reference_binary"] = ref
     others = {}
     for wl in extra_scenes:
         if wl == workload:
             continue
         sc = getattr(rt.scenes, WORKLOADS[wl][0])()
         others[wl] = {"all_cores": cpu_sample(sc, seconds / 3, cores), "one_thread": cpu_sample(sc, seconds / 3, 1)}
+        if wl == "c1":
+            ref = reference_binary()
+            if ref:
+                others[wl]["reference_binary"] = ref
     if others:
         out["other_scenes"] = others
     return out
