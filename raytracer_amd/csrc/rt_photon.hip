@@ -674,12 +674,14 @@ rt_trace_kernel(const TraceArgs a)
 // RT_MAX_STEPS = 2^22. Here a count per photon would be one more word to carry between the owner and the serving
 // lane every round, so the guard is kept in time instead: every kTickRounds-th round of the wave is a tick (wave-
 // uniform), a photon served by a stepping stage in a tick round ages by one (5 bits of the record), and one that
-// is still there at age 31 is abandoned (RT_EV_ABORT; rt_synchronize reports it) -- after about 31 * 2^17 = 2^22
-// rounds of its wave, the same order as the step limit. A photon is served at most once per round, so no photon
-// is retired before it has had the chance of that many steps only if it is served every round; a photon of a
-// valid run ends after tens of steps and at most a handful of ticks can pass in a wave's whole life (a launch of
-// 2^28 photons is about 2 * 10^4 rounds per wave), so the guard cannot fire on one. Non-finite positions are
-// caught in the step itself, at once.
+// is still there at age 31 is abandoned (RT_EV_ABORT; rt_synchronize reports it) -- after at least 31 * 2^21 =
+// 6.5 * 10^7 rounds of its wave. A photon is served at most once per round and takes at most two steps when it is,
+// so this guard is always the LOOSER of the two: it must never retire a photon that the step limit would let
+// finish. (It did once: with ticks every 2^17 rounds a conservative, optically very thick planar scene of the
+// randomised sweep -- 39 000 scatterings per photon on average, the longest above a million -- lost 16 of 60 000
+// photons that the oracle traced to their end, because a photon in a pool of 192 is served only every third round.)
+// A photon of an ordinary run ends after tens of steps (a launch of 2^28 photons is about 10^4 rounds per wave).
+// Non-finite positions are caught in the step itself, at once.
 // (state >> 2 is the stage that serves it: 0 traverse, 1 event, 3 launch, 4 slab; class 2 was round 1's new-direction stage)
 // PS_LAUNCH_TALLY: a free slot whose last photon was absorbed in the air; word 0 of its record holds the tally word
 // that the next launch round adds to (see the event stage)
@@ -687,7 +689,7 @@ enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_LAUNCH = 1
 enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
 constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
-constexpr uint32_t kTickRounds = 1u << 17;
+constexpr uint32_t kTickRounds = 1u << 21;
 #ifndef RT_FUSE_LAUNCH
 #define RT_FUSE_LAUNCH 1
 #endif

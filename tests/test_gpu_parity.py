@@ -407,6 +407,38 @@ def test_regression_zero_majorant_region_with_zero_optical_depth(rt, pool):
     tr.close()
 
 
+def test_regression_long_lived_photons_are_not_abandoned(rt):
+    """Case 105744 of tools/fuzz_parity.py: a conservative, optically very thick planar scene (23 x 20 x 18 cells,
+    zenith 88 degrees) in which a photon scatters 39 000 times on average and the longest more than a million times.
+    The pool kernel's step guard counts rounds of the wave, not steps of the photon; with a tick every 2^17 rounds it
+    abandoned 16 of these 60 000 photons that the oracle (limit: 2^22 steps per photon) traces to their end. Expected
+    values: oracle/photon_oracle.c on the same case (32 s on 8 threads, so not repeated here): event counts, tally
+    sums and the md5 of every tally array."""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    scene, kind = fuzz_parity.random_scene(np.random.default_rng(1000 + 105744))
+    assert kind == "to_ground" and (scene.itot, scene.jtot, scene.ktot) == (23, 20, 18)
+    tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=192, levels=5, merge_tau_milli=500, launch_log2k=2, planar=1,
+                                    fixed_dot=1, chunk=256, th_launch=40)
+    tr.set_supergrid(2, 4, 7)
+    tr.trace(3557997916280079263, 100261457747, 60000)
+    tr.synchronize()                      # raises if any photon was abandoned
+    got, ev = tr.tallies(), tr.events()
+    tr.close()
+    assert ev == {"steps": 2335813323, "collision_tests": 2335752934, "real": 1923765898, "scatter": 1923765898,
+                  "cloud_scatter": 1923765898, "surface": 1971, "toa": 58418, "absorb": 0, "transition": 60389, "abort": 0}
+    assert {n: int(got[n].sum()) for n in O.TALLY_NAMES} == {
+        "toa_down": 60000, "toa_up": 58418, "surface_down_direct": 0, "surface_down_diffuse": 1971, "surface_up": 389,
+        "atmos_direct": 0, "atmos_diffuse": 0}
+    assert {n: hashlib.md5(got[n].tobytes()).hexdigest()[:12] for n in O.TALLY_NAMES} == {
+        "toa_down": "227254863162", "toa_up": "b00773494a8a", "surface_down_direct": "c47e8c474dbc",
+        "surface_down_diffuse": "0b0c91e7a17b", "surface_up": "207ccf803fcb", "atmos_direct": "77c4592db1af",
+        "atmos_diffuse": "77c4592db1af"}
+
+
 def test_errors_are_reported_not_fatal(rt):
     with pytest.raises(rt.RtError):
         rt.PhotonTracer(0, 4, 4, 1.0, 1.0, 1.0)

@@ -85,8 +85,12 @@ def main():
                                         th_launch=thl, launch_sort=sort, sort_tile_log2=sort_tile,
                                         sort_batch_log2=sort_batch, launch_tile_log2=ltile)
         tr.set_supergrid(*sg)
-        tr.trace(seed, pid0, n)
-        tr.synchronize()
+        try:
+            tr.trace(seed, pid0, n)
+            tr.synchronize()
+        except Exception as exc:
+            print("ERROR", desc, "seed:", seed, exc, flush=True)
+            return 1
         got, gev = tr.tallies(), tr.events()
         tr.close()
         want, wev = O.photon_oracle(scene, seed, pid0, n, fixed_dot=fixed_dot, supergrid=sg, launch_log2k=log2k,
