@@ -47,7 +47,8 @@
 
 #define RT_EPS 1.1920928955078125e-07f /* FLT_EPSILON, raytracer_kernels.cu:24 */
 #define RT_TWO_PI 6.2831854820251465f   /* Float(2.*M_PI) */
-#define RT_MAX_STEPS (1u << 22)
+#define RT_MAX_STEPS (1u << 24) /* guard against a photon that never ends: the reference has none; the kernels' guards are this
+                                   one (lane-resident kernel) or looser (pool kernel, by rounds of the wave) */
 
 
 /* ---------------------------------------------------------------- Philox4x32-10 ---------- */

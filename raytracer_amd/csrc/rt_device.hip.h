@@ -24,7 +24,8 @@
 
 #define RT_EPS 1.1920928955078125e-07f   // FLT_EPSILON (Float_epsilon, raytracer_kernels.cu:24)
 #define RT_TWO_PI 6.2831854820251465f    // Float(2.*M_PI)
-#define RT_MAX_STEPS (1u << 22)          // per-photon iteration guard: every wave must drain
+#define RT_MAX_STEPS (1u << 24)          // per-photon iteration guard (every wave must drain); the pool kernel packs a
+                                         // photon's event index into 24 bits, and an event takes a step
 
 namespace rt
 {

@@ -671,7 +671,7 @@ rt_trace_kernel(const TraceArgs a)
 //
 // Step guard. Every wave must drain, so a photon that never ends (a non-finite state, or a bug that makes it
 // cross faces forever) has to be retired: the lane-resident kernel and the oracle count its steps up to
-// RT_MAX_STEPS = 2^22. Here a count per photon would be one more word to carry between the owner and the serving
+// RT_MAX_STEPS = 2^24. Here a count per photon would be one more word to carry between the owner and the serving
 // lane every round, so the guard is kept in time instead: every kTickRounds-th round of the wave is a tick (wave-
 // uniform), a photon served by a stepping stage in a tick round ages by one (5 bits of the record), and one that
 // is still there at age 31 is abandoned (RT_EV_ABORT; rt_synchronize reports it) -- after at least 31 * 2^21 =
