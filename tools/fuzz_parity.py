@@ -19,10 +19,12 @@ import oracle_lib as O          # noqa: E402
 import raytracer_amd as rt      # noqa: E402
 
 
-def random_scene(rng):
+def random_scene(rng, large=False):
     S = rt.scenes
     f = np.float32
     itot, jtot, ktot = int(rng.integers(3, 41)), int(rng.integers(3, 41)), int(rng.integers(2, 25))
+    if large:       # sides that are whole numbers of 32-column tiles: the tiled launch orders and many sort tiles
+        itot, jtot, ktot = 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 6)), int(rng.integers(8, 41))
     dx, dy, dz = float(rng.uniform(20, 200)), float(rng.uniform(20, 200)), float(rng.uniform(10, 120))
     ztop = ktot * dz
     kind = rng.choice(["clouds", "deck", "clear", "to_ground", "to_top", "everywhere"])
@@ -58,7 +60,9 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     for case in range(first, first + cases):
         rng = np.random.default_rng(1000 + case)
-        scene, kind = random_scene(rng)
+        rng2 = np.random.default_rng(77000 + case)          # options added later: a stream of its own, so that the
+        large = case >= 400000 and rng2.random() < 0.15     # cases of earlier sweeps keep their definitions
+        scene, kind = random_scene(rng, large)
         pool = int(rng.choice([0, 64, 96, 128, 128, 160, 192, 256]))
         sg = (0, 0, 0) if rng.random() < 0.15 else tuple(int(v) for v in rng.integers(1, 9, size=3))
         levels = int(rng.integers(0, 6))
@@ -71,10 +75,9 @@ def main():
         n = int(rng.choice([1, 63, 1000, 20000, 60000]))
         pid0 = int(rng.integers(0, 1 << 39))
         seed = int(rng.integers(0, 1 << 62))
-        rng2 = np.random.default_rng(77000 + case)          # launch sort (round 2): a stream of its own, so that the
-        sort = int(rng2.choice([-1, 0, 1, 1]))              # cases of earlier sweeps keep their definitions
+        sort = int(rng2.choice([-1, 0, 1, 1]))              # launch sort (round 2)
         sort_tile, sort_batch = int(rng2.integers(0, 7)), int(rng2.choice([16, 28]))
-        tiles = [t for t in (0, 1, 2, 3) if scene.itot % (1 << t) == 0 and scene.jtot % (1 << t) == 0]
+        tiles = [t for t in ((0, 1, 2, 3, 4, 5) if large else (0, 1, 2, 3)) if scene.itot % (1 << t) == 0 and scene.jtot % (1 << t) == 0]
         ltile = int(rng2.choice(tiles)) if log2k >= 0 else 0          # tiled stratified launch order
         stats = 1
         if case >= 300000:       # later additions (earlier case numbers keep their definitions): the kernels without
