@@ -93,8 +93,15 @@ def main():
                                         th_launch=thl, launch_sort=sort, sort_tile_log2=sort_tile,
                                         sort_batch_log2=sort_batch, launch_tile_log2=ltile)
         tr.set_supergrid(*sg)
-        try:
-            tr.trace(seed, pid0, n)
+        cuts = [0, n]
+        if case >= 500000 and n > 2 and rng2.random() < 0.3:        # the range in two or three calls that accumulate,
+            cuts = sorted({0, n, *(int(c) for c in rng2.integers(1, n, size=int(rng2.integers(1, 3))))})   # the later
+        try:                                                        # ones through the entry point that allocates nothing
+            for piece, (b, e) in enumerate(zip(cuts, cuts[1:])):
+                if piece > 0 and pool > 0:
+                    tr.trace_noalloc(seed, pid0 + b, e - b)
+                else:
+                    tr.trace(seed, pid0 + b, e - b)
             tr.synchronize()
         except Exception as exc:
             print("ERROR", desc, "seed:", seed, exc, flush=True)
