@@ -10,6 +10,9 @@ cpu_ref_c3_1e8.npz    oracle/cpu_ref.cpp (bit-pinned to raytracer_3d.cpp by cpu_
                       scenes.cumulus_c3(), >= 1.2*10^8 photons, 8 threads: sums, per-level sums, 4x4 blocks.
 cpu_ref_c4_6e7.npz    the same on scenes.cumulus_c4() (1024x1024x128), >= 6*10^7 photons: sums, per-level
                       sums, 16x16-column-block sums.
+cpu_ref_sun0_5e7.npz, cpu_ref_sun75_5e7.npz   the same on a 96x80x48 cumulus scene under two other suns: overhead
+                      (zenith 0, azimuth 0: two direction components exactly zero) over a bright surface (albedo 0.7),
+                      and low (zenith 75, azimuth 213) over a black one; 5*10^7 photons each, 2x2-column blocks.
 Each file also holds the md5 of the scene's four float32 fields, so a drifting scene generator is noticed.
 Fixtures are counts only; no reference source is stored."""
 import hashlib
@@ -49,7 +52,13 @@ def summary(t, block):
     return out
 
 
-which = sys.argv[1:] or ["c1", "c3", "c4"]
+def other_sun(zenith, azimuth, albedo):
+    sc = scenes.cumulus(96, 80, 48, 50.0, 50.0, 25.0, n_clouds=12, seed=3, z_base=300.0, z_top=900.0)
+    sc.zenith_deg, sc.azimuth_deg, sc.albedo = zenith, azimuth, albedo
+    return sc
+
+
+which = sys.argv[1:] or ["c1", "c3", "c4", "sun0", "sun75"]
 if "c1" in which:
     t0 = time.time()
     with tempfile.TemporaryDirectory() as d:
@@ -63,7 +72,9 @@ if "c1" in which:
     np.savez_compressed(os.path.join(HERE, "reference_c1_2e8.npz"), **s)
     print("c1", int(r["toa_down"].sum()), "photons", time.time() - t0, "s", flush=True)
 for key, factory, n, block, fname in (("c3", scenes.cumulus_c3, 120_000_000, 4, "cpu_ref_c3_1e8.npz"),
-                                      ("c4", scenes.cumulus_c4, 60_000_000, 16, "cpu_ref_c4_6e7.npz")):
+                                      ("c4", scenes.cumulus_c4, 60_000_000, 16, "cpu_ref_c4_6e7.npz"),
+                                      ("sun0", lambda: other_sun(0.0, 0.0, 0.7), 50_000_000, 2, "cpu_ref_sun0_5e7.npz"),
+                                      ("sun75", lambda: other_sun(75.0, 213.0, 0.0), 50_000_000, 2, "cpu_ref_sun75_5e7.npz")):
     if key not in which:
         continue
     t0 = time.time()

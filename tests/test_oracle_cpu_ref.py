@@ -81,8 +81,11 @@ def test_large_fixtures_are_consistent_with_the_small_ones():
     levs = np.array(small["atmos_level_sums"], dtype=np.float64)
     z = (lev / n - levs / ns) / np.sqrt(levs / ns * (1 / n + 1 / ns))
     assert np.max(np.abs(z)) < 5 and 0.6 < np.mean(z ** 2) < 1.5
+    small_scene = lambda: scenes.cumulus(96, 80, 48, 50.0, 50.0, 25.0, n_clouds=12, seed=3, z_base=300.0, z_top=900.0)
     for fname, factory, floor in (("reference_c1_2e8.npz", scenes.block_cloud, 200_000_000),
-                                  ("cpu_ref_c3_1e8.npz", scenes.cumulus_c3, 120_000_000)):
+                                  ("cpu_ref_c3_1e8.npz", scenes.cumulus_c3, 120_000_000),
+                                  ("cpu_ref_sun0_5e7.npz", small_scene, 50_000_000),
+                                  ("cpu_ref_sun75_5e7.npz", small_scene, 50_000_000)):
         f = np.load(os.path.join(GOLD, fname))
         s = [int(v) for v in f["sums"]]
         assert s[0] >= floor and s[0] == s[2] + s[3] - s[4] + s[1] + s[5] + s[6]              # photon balance
