@@ -19,10 +19,12 @@ import oracle_lib as O          # noqa: E402
 import raytracer_amd as rt      # noqa: E402
 
 
-def random_scene(rng, large=False):
+def random_scene(rng, large=False, degenerate=False):
     S = rt.scenes
     f = np.float32
     itot, jtot, ktot = int(rng.integers(3, 41)), int(rng.integers(3, 41)), int(rng.integers(2, 25))
+    if degenerate:  # one or two cells along some axes: a single column, a single level, the planar grid (jtot = 1)
+        itot, jtot, ktot = int(rng.integers(1, 5)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
     if large:       # sides that are whole numbers of 32-column tiles: the tiled launch orders and many sort tiles
         itot, jtot, ktot = 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 6)), int(rng.integers(8, 41))
     dx, dy, dz = float(rng.uniform(20, 200)), float(rng.uniform(20, 200)), float(rng.uniform(10, 120))
@@ -62,7 +64,8 @@ def main():
         rng = np.random.default_rng(1000 + case)
         rng2 = np.random.default_rng(77000 + case)          # options added later: a stream of its own, so that the
         large = case >= 400000 and rng2.random() < 0.15     # cases of earlier sweeps keep their definitions
-        scene, kind = random_scene(rng, large)
+        degenerate = case >= 700000 and not large and rng2.random() < 0.15
+        scene, kind = random_scene(rng, large, degenerate)
         pool = int(rng.choice([0, 64, 96, 128, 128, 160, 192, 256]))
         sg = (0, 0, 0) if rng.random() < 0.15 else tuple(int(v) for v in rng.integers(1, 9, size=3))
         levels = int(rng.integers(0, 6))
