@@ -272,8 +272,18 @@ __device__ __forceinline__ void launch_column(const TraceArgs& a, uint32_t c, ui
 __device__ __forceinline__ uint32_t launch_column_index_exact(int log2k, uint32_t ncol, uint64_t pid, uint32_t key0, uint32_t key1)
 {
     const uint64_t qt = pid >> log2k;
-    const uint64_t pass = qt / ncol;
-    const uint32_t q = (uint32_t)(qt - pass * ncol);
+    uint64_t pass;
+    uint32_t q;
+    if ((ncol & (ncol - 1u)) == 0u)        // (wave-uniform) a power-of-two number of columns: no 64-bit division
+    {
+        pass = qt >> (31 - __builtin_clz(ncol));
+        q = (uint32_t)qt & (ncol - 1u);
+    }
+    else
+    {
+        pass = qt / ncol;
+        q = (uint32_t)(qt - pass * ncol);
+    }
     uint32_t c = q + launch_pass_offset(pass, ncol, key0, key1);      // < 2 * ncol < 2^32
     if (c >= ncol) c -= ncol;
     return c;
