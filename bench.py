@@ -174,6 +174,12 @@ def cpu_baseline(scene, seconds, workload, extra_scenes):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a five-line version banner at
+    # its first collective), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the
+    # saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -393,7 +399,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
