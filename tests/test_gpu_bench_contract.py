@@ -1,0 +1,51 @@
+"""bench.py's contract with the driver: ONE JSON line on stdout, with the metric, the roofline object and (when asked
+for) the CPU baseline -- a small workload, as a subprocess, the way the driver runs it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--photons-log2", "22",
+                        "--steps", "2", "--warmup", "1", *extra], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    return json.loads(lines[0])
+
+
+def test_one_json_line_with_roofline_and_cpu_baseline():
+    d = _run("--cpu-seconds", "2", "--cpu-scenes", "c1")
+    assert d["metric"] == "photons/sec (whole node)" and d["unit"] == "photons/s" and d["n_gpus"] == 1
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 1e8 and abs(d["value"] - (1 << 22) / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["kernel_ms"] > 0
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 1e4 and cpu["one_thread"]["cores"] == 1
+    assert "sample" in cpu and "cpu_model" in cpu
+    if "reference_binary" in cpu:          # the compiled reference travels with the tree when it was built
+        assert cpu["reference_binary"]["all_cores"]["kind"] == "reference"
+    assert d["uniform_launch"]["balance"] == 0 and d["uniform_launch"]["value"] > 1e8
+
+
+def test_collective_path_keeps_stdout_clean():
+    """--force-dist runs the step with the RCCL all-reduce at world size 1; RCCL's banner must not reach stdout."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--photons-log2", "22",
+                        "--steps", "2", "--warmup", "1", "--force-dist", "--no-cpu-baseline", "--no-uniform-leg"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert "RCCL all-reduce" in d["config"]["workload"] and d["value"] > 1e8
