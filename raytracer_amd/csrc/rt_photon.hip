@@ -145,8 +145,8 @@ struct TraceArgs
     uint32_t launch_div, launch_tile_log2;    // launch_div = itot, or the tiles per row of a tiled launch order
 };
 
-// Kernel arguments of the pool tracer: only what its three frequent stages (traverse, event, new direction) use
-// in every round. The wave's loop is short of scalar registers (every spilled one costs a v_readlane per use), so
+// Kernel arguments of the pool tracer: only what the traverse step -- the traverse stage's, and the one at the end
+// of the event stage -- uses in every round. The wave's loop is short of scalar registers (every spilled one costs a v_readlane per use), so
 // everything the rare stages need -- launch, slab stage, surface event, the abort path, statistics -- lives in
 // the ColdBlock in device memory and is fetched with scalar loads where it is used.
 struct PoolArgs
@@ -204,8 +204,8 @@ __device__ __forceinline__ ColdPtr cold_of(const PoolArgs& a)
 // reads of it are scalar loads issued inside that stage, not values held in scalar registers across the whole
 // loop (which is short of them: held there, they were spilled to VGPR lanes and read back with v_readlane, 16 per
 // event round). Used by the event stage for ITS arguments (cells, tallies, grid dimensions and reciprocal
-// spacings) and by the rare launch and slab stages for all of theirs; the traverse and new-direction stages keep
-// their arguments in registers (`a.`): loading those per round as well costs more in exposed scalar-load latency
+// spacings) and by the rare launch and slab stages for all of theirs; the traverse step keeps
+// its arguments in registers (`a.`): loading those per round as well costs more in exposed scalar-load latency
 // than the spills did (measured on C4: all stages opaque 45.5 ms, none 44.3 ms, this split 43.6 ms).
 typedef const __attribute__((address_space(4))) PoolArgs* ArgPtr;
 __device__ __forceinline__ ArgPtr args_now()
@@ -667,11 +667,9 @@ rt_trace_kernel(const TraceArgs a)
 //   g0 {x, y, z, tau}          tau holds 1/M of the region while the photon waits for its collision event
 //                              (the event stage draws the next tau before anything reads it)
 //   g1 {ux, uy, uz, ci | cj << 16}
-//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | from_cloud << 25 | alt << 26 | age << 27}
-//                              alt tells the two states of a stage apart (surface event, not collision;
-//                              reflection, not scattering): set by the slab stage on arrival at the surface
-//                              While a photon waits for stage S the first three hold {asy, u_mu, u_phi}: the
-//                              reciprocals are dead then. slab is a signed byte: -1 (below the surface) and
+//   g2 {1/ux, 1/uy, 1/uz, ck | slab << 16 | diffuse << 24 | alt << 26 | age << 27}
+//                              alt tells the two states of the event stage apart (surface event, not collision):
+//                              set by the slab stage on arrival at the surface. slab is a signed byte: -1 (below the surface) and
 //                              nslab (above the domain top) while a photon that has just left the atmosphere
 //                              waits for the slab stage. age is the step guard (below)
 // and, in three registers of the lane that owns the slot (slot h * 64 + lane; read with ds_bpermute by the lane
