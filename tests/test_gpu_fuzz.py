@@ -37,3 +37,18 @@ def test_random_scenes_and_options_bit_identical_to_oracle(rt, first, capsys):
     out = capsys.readouterr().out
     assert rc == 0, out
     assert "20 cases bit-identical" in out
+
+
+def test_random_driver_runs_bit_identical_to_oracle(rt, capsys):
+    """A slice of tools/fuzz_drivers.py: the C++ driver raytracer_3d_io_gpu on random scenes with random --seed,
+    --launch, --launch-tile and --resume splits against the oracle (the tool was run over 750 cases)."""
+    import fuzz_drivers
+    argv = sys.argv
+    sys.argv = ["fuzz_drivers.py", "12", "1000"]
+    try:
+        rc = fuzz_drivers.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    assert rc == 0, out
+    assert "12 driver cases bit-identical" in out
