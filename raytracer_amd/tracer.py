@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 
 import numpy as np
 
@@ -46,6 +47,17 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch-ROCm brings its own HIP runtime and this library uses the system's. Both work in one process when
+    # torch's is initialised FIRST; the other way round torch finds "No HIP GPUs". So if torch is already imported,
+    # let it initialise before this library makes its first HIP call (a process that imports torch only later must
+    # do `import torch; torch.cuda.init()` before it creates a PhotonTracer: INTEGRATION.md).
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, f32p, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint64)
     sig = {

@@ -11,3 +11,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_initialises_hip_first():
+    """On a GPU box PyTorch's HIP runtime has to be initialised before the library's first HIP call (the other order
+    leaves torch without a GPU: INTEGRATION.md); tests that use both may run in any order and alone."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
