@@ -1,6 +1,6 @@
 """Randomised parity on the GPU: a slice of tools/fuzz_parity.py (random ragged scenes x random options x random
 photon ID ranges; HIP kernels against oracle/photon_oracle.c, tallies and event counters bit for bit). The tool
-itself was run over 3 400 cases on the round-1 kernel and some 350 000 on round 2's ("Randomised
+itself was run over 3 400 cases on the round-1 kernel and some 570 000 on round 2's ("Randomised
 parity"); the suite keeps 180 of them, half from the ranges whose cases also draw the options added in round 2
 (launch sort, tiled launch order, counter-free kernels, several sort batches, 32-column tiles, split calls through
 rt_trace_noalloc)."""
@@ -41,7 +41,7 @@ def test_random_scenes_and_options_bit_identical_to_oracle(rt, first, capsys):
 
 def test_random_driver_runs_bit_identical_to_oracle(rt, capsys):
     """A slice of tools/fuzz_drivers.py: the C++ driver raytracer_3d_io_gpu on random scenes with random --seed,
-    --launch, --launch-tile and --resume splits against the oracle (the tool was run over 750 cases)."""
+    --launch, --launch-tile and --resume splits against the oracle (the tool was run over 3 250 cases)."""
     import fuzz_drivers
     argv = sys.argv
     sys.argv = ["fuzz_drivers.py", "12", "1000"]
