@@ -13,6 +13,9 @@ cpu_ref_c4_6e7.npz    the same on scenes.cumulus_c4() (1024x1024x128), >= 6*10^7
 cpu_ref_sun0_5e7.npz, cpu_ref_sun75_5e7.npz   the same on a 96x80x48 cumulus scene under two other suns: overhead
                       (zenith 0, azimuth 0: two direction components exactly zero) over a bright surface (albedo 0.7),
                       and low (zenith 75, azimuth 213) over a black one; 5*10^7 photons each, 2x2-column blocks.
+reference_2d_2e8.npz  the COMPILED 2D REFERENCE, `oracle/_ref/raytracer_2d_ref 2000` (2*10^8 photons of the built-in scene
+                      of raytracer.cpp, 8 threads): sums of its six tallies, the five 1-D tallies per column, and
+                      its atmos array (128 levels x 256 columns, direct + diffuse) cell by cell.
 Each file also holds the md5 of the scene's four float32 fields, so a drifting scene generator is noticed.
 Fixtures are counts only; no reference source is stored."""
 import hashlib
@@ -58,7 +61,17 @@ def other_sun(zenith, azimuth, albedo):
     return sc
 
 
-which = sys.argv[1:] or ["c1", "c3", "c4", "sun0", "sun75"]
+which = sys.argv[1:] or ["c1", "c3", "c4", "sun0", "sun75", "2d"]
+if "2d" in which:
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as d:
+        r = O.run_reference_binary_2d(2000, d, 8)
+    s2 = {"sums": np.array([int(r[n].sum()) for n in O.TALLY_NAMES_2D], dtype=np.uint64),
+          "atmos": r["atmos"].astype(np.uint32), "threads": np.array(8)}
+    for n in O.TALLY_NAMES_2D[:5]:
+        s2["columns_" + n] = r[n].astype(np.uint64)
+    np.savez_compressed(os.path.join(HERE, "reference_2d_2e8.npz"), **s2)
+    print("2d", int(r["toa_down"].sum()), "photons", time.time() - t0, "s", flush=True)
 if "c1" in which:
     t0 = time.time()
     with tempfile.TemporaryDirectory() as d:

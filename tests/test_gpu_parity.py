@@ -615,6 +615,41 @@ def test_other_suns_and_surfaces_against_reference_restatement(rt, zenith, azimu
     _check_against_fixture(t, n, fixture, scene, {"blocks": blocks})
 
 
+def test_planar_mode_2p28_photons_against_the_compiled_2d_reference(rt):
+    """SURVEY.md section 8 f4 at statistics: the 2D tracer as the jtot = 1 grid with option planar, 2^28 photons,
+    against 2*10^8 photons of the COMPILED 2D REFERENCE (oracle/_ref/raytracer_2d_ref 2000; fixture
+    reference_2d_2e8.npz): exact balance, global fractions within 4 sigma, z-scores per column of the four
+    outgoing 1-D tallies, per level and per cell (128 x 256) of the absorption."""
+    from test_oracle_2d import scene_2d
+    scene = scene_2d()
+    g = np.load(__import__("os").path.join(GOLDEN, "reference_2d_2e8.npz"))
+    n = 1 << 28
+    tr = rt.PhotonTracer.from_scene(scene, planar=1)
+    tr.trace(11, 0, n); tr.synchronize()
+    t = tr.tallies()
+    tr.close()
+    assert rt.photon_balance(t) == 0 and int(t["toa_down"].sum()) == n
+    names = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up")
+    sums = dict(zip(names + ("atmos",), (int(v) for v in g["sums"])))
+    nb = sums["toa_down"]
+    atmos = (t["atmos_direct"] + t["atmos_diffuse"])[:, 0, :]
+    mine = {k: int(t[k].sum()) for k in names[1:]}
+    mine["atmos"] = int(atmos.sum())
+    for name, v in mine.items():
+        pa, pb = v / n, sums[name] / nb
+        sig = np.sqrt(pb * (1 - pb) * (1 / n + 1 / nb))
+        assert abs(pa - pb) < 4 * sig, (name, pa, pb, (pa - pb) / sig)
+    zs = [_z(t[name][0], n, g["columns_" + name], nb) for name in names[1:]]
+    for name, z in zip(names[1:], zs):
+        assert z.size > 200 and np.max(np.abs(z)) < 5.0 and 0.7 < np.mean(z ** 2) < 1.3, (name, np.mean(z ** 2), np.max(np.abs(z)))
+    zl = _z(atmos.sum(axis=1), n, g["atmos"].sum(axis=1), nb)
+    assert zl.size > 100 and np.max(np.abs(zl)) < 5.0 and 0.6 < np.mean(zl ** 2) < 1.4, (np.mean(zl ** 2), np.max(np.abs(zl)))
+    zc = _z(atmos, n, g["atmos"], nb)
+    assert zc.size > 20000 and np.max(np.abs(zc)) < 6.0 and 0.95 < np.mean(zc ** 2) < 1.05, (zc.size, np.mean(zc ** 2), np.max(np.abs(zc)))
+    zall = np.concatenate(zs + [zl, zc])
+    assert abs(np.mean(zall)) < 4 / np.sqrt(zall.size), np.mean(zall)
+
+
 def test_c2_clear_sky_closure_at_full_size(rt):
     """BASELINE config 2: clear-sky Rayleigh column, 2^24 photons. Conservative gas absorbs nothing
     in the air; absorbing gas gives the Beer-Lambert direct beam exp(-tau/mu0) at the surface."""

@@ -70,3 +70,20 @@ def test_planar_float_oracle_agrees_with_2d_reference_statistics():
     t3, _ = O.photon_oracle(scene_2d(), 3, 0, 200_000, planar=False)
     tp, _ = O.photon_oracle(scene_2d(), 3, 0, 200_000, planar=True)
     assert any(not np.array_equal(t3[k], tp[k]) for k in O.TALLY_NAMES)
+
+
+def test_large_2d_fixture_is_consistent(run_100k):
+    """tests/golden/reference_2d_2e8.npz (make_golden_large.py: 2*10^8 photons of the compiled 2D reference): the
+    sums are those of the stored arrays, the photons balance, and a fresh 10^5-photon run of the restatement falls
+    within 4 sigma of its fractions."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_2d_2e8.npz"))
+    s = dict(zip(O.TALLY_NAMES_2D, (int(v) for v in g["sums"])))
+    assert s["toa_down"] >= 200_000_000
+    assert s["toa_down"] == s["surface_down_direct"] + s["surface_down_diffuse"] - s["surface_up"] + s["toa_up"] + s["atmos"]
+    assert int(g["atmos"].sum(dtype=np.int64)) == s["atmos"] and g["atmos"].shape == (128, 256)
+    for name in O.TALLY_NAMES_2D[:5]:
+        assert int(g["columns_" + name].sum(dtype=np.int64)) == s[name] and g["columns_" + name].size == 256
+    n, nb = int(run_100k["toa_down"].sum()), s["toa_down"]
+    for name in O.TALLY_NAMES_2D[1:]:
+        p, q = int(run_100k[name].sum()) / n, s[name] / nb
+        assert abs(p - q) < 4 * np.sqrt(q * (1 - q) * (1 / n + 1 / nb)), name
