@@ -206,7 +206,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+            # RCCL over xGMI; its stream at high priority, so that the all-reduce kernel (which needs whole SIMDs'
+            # worth of registers, raytracer_amd/distributed.py) is placed ahead of the next trace's workgroups
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group("gloo")
 

@@ -63,9 +63,14 @@ def trace_sharded(tracer, tally_tensor, seed: int, total_photons: int, first_pho
     return first_photon_id + begin, count
 
 
-# resident waves per CU of the pool kernel while a collective may be pending: leaves 160 - 22 * 6.1 = 26 KiB of
-# every CU's LDS free, more than RCCL's gfx950 kernels ask for (21 184 B), so the all-reduce kernel is placed at once
-# instead of waiting for a whole trace (profiles/r1_overlap_probe.txt); costs the trace about 4 %
+# Resident waves per CU of the pool kernel that leave 160 - 22 * 6.1 = 26 KiB of every CU's LDS free (option
+# reserve_lds, off by default). Round 2 first capped the tracer at this whenever a collective could be pending, after
+# a probe with an LDS-only stand-in kernel (profiles/r1_overlap_probe.txt). The metadata of RCCL's own gfx950 code
+# objects says that cannot work: rcclGenericKernel, the kernel behind every ring/tree collective, asks for 19 744 B of
+# LDS AND 261-280 registers per lane (profiles/r2_rccl_kernel_resources.txt), so its 4-wave workgroup needs every SIMD
+# of a CU down to 3 pool waves (12 per CU), not 22. The cap cost the trace 4 % and bought nothing, so the overlap
+# rests on order instead: the all-reduce becomes ready when the narrowing kernel ends, the next trace only after the
+# 2 GiB tally memset that follows it in the stream (about 0.5 ms), and bench.py gives RCCL a high-priority stream.
 POOL_WAVES_BESIDE_A_COLLECTIVE = 22
 
 
@@ -83,7 +88,7 @@ class ShardedTracer:
     exchange on the 64-bit buffer, which the widening kernel then has left untouched."""
 
     def __init__(self, tracer, device, group=None, overlap=None, wire32=True, force_collective=False,
-                 reserve_lds=True):
+                 reserve_lds=False):
         import torch
         self.torch = torch
         self.tracer, self.group = tracer, group

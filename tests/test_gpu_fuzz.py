@@ -1,9 +1,10 @@
 """Randomised parity on the GPU: a slice of tools/fuzz_parity.py (random ragged scenes x random options x random
 photon ID ranges; HIP kernels against oracle/photon_oracle.c, tallies and event counters bit for bit). The tool
 itself was run over 3 400 cases on the round-1 kernel and some 570 000 on round 2's ("Randomised
-parity"); the suite keeps 180 of them, half from the ranges whose cases also draw the options added in round 2
+parity"); the suite keeps 200 of them, half from the ranges whose cases also draw the options added in round 2
 (launch sort, tiled launch order, counter-free kernels, several sort batches, 32-column tiles, split calls through
-rt_trace_noalloc)."""
+rt_trace_noalloc; from case 1 100 000 any sun and surface, and a context used twice: a new sun or new optics, counts
+accumulating on the device or through rt_download_tallies / rt_upload_tallies)."""
 import os
 import sys
 
@@ -24,7 +25,7 @@ def rt():
     return raytracer_amd
 
 
-@pytest.mark.parametrize("first", [0, 1000, 2000, 3000, 300000, 400000, 500000, 543210, 700000])
+@pytest.mark.parametrize("first", [0, 1000, 2000, 3000, 300000, 400000, 500000, 543210, 700000, 1100000])
 def test_random_scenes_and_options_bit_identical_to_oracle(rt, first, capsys):
     import fuzz_parity
     argv = sys.argv

@@ -87,10 +87,25 @@ def main():
             stats = int(rng2.random() < 0.5)        # event counters (what production runs), and calls of several sort batches
             if rng2.random() < 0.08:
                 n = int(rng2.choice([70001, 150001, 262144]))
+        second = None
+        if case >= 1100000:      # any sun and surface, tiles too large for the sort's toa_down pass, and a context that is
+            rng3 = np.random.default_rng(55000 + case)      # used twice: a new sun or new optics, counts accumulating
+            if rng3.random() < 0.5:
+                scene.zenith_deg = float(rng3.uniform(0.0, 89.5))
+                scene.azimuth_deg = float(rng3.uniform(0.0, 360.0))
+                scene.albedo = float(rng3.uniform(0.0, 1.0))
+            if rng3.random() < 0.3:
+                sort_tile = int(rng3.integers(5, 10))
+            if rng3.random() < 0.35:
+                second = dict(kind=str(rng3.choice(["sun", "optics", "both"])), zenith=float(rng3.uniform(0.0, 89.5)),
+                              azimuth=float(rng3.uniform(0.0, 360.0)), albedo=float(rng3.choice([0.0, 0.35, 1.0])),
+                              scale=float(rng3.choice([0.25, 3.0])), n=int(rng3.choice([1, 999, 30000])),
+                              seed=int(rng3.integers(0, 1 << 62)), upload=bool(rng3.random() < 0.5))
         desc = dict(case=case, kind=kind, grid=(scene.itot, scene.jtot, scene.ktot), albedo=scene.albedo, zenith=scene.zenith_deg,
                     pool=pool, supergrid=sg, levels=levels, tau_milli=tau_milli, log2k=log2k, planar=planar,
                     fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0, stats=stats,
-                    launch_sort=sort, sort_tile_log2=sort_tile, sort_batch_log2=sort_batch, launch_tile_log2=ltile)
+                    launch_sort=sort, sort_tile_log2=sort_tile, sort_batch_log2=sort_batch, launch_tile_log2=ltile,
+                    second=second)
         tr = rt.PhotonTracer.from_scene(scene, stats=stats, pool=pool, levels=levels, merge_tau_milli=tau_milli,
                                         launch_log2k=log2k, planar=int(planar), fixed_dot=int(fixed_dot), chunk=chunk,
                                         th_launch=thl, launch_sort=sort, sort_tile_log2=sort_tile,
@@ -106,6 +121,29 @@ def main():
                 else:
                     tr.trace(seed, pid0 + b, e - b)
             tr.synchronize()
+            scene2 = None
+            if second is not None:
+                S = rt.scenes
+                scene2 = scene
+                if second["kind"] in ("optics", "both"):        # thinner or thicker clouds, darker droplets
+                    kc = (scene.k_cloud * np.float32(second["scale"])).astype(np.float32)
+                    ssa, asy = S._mix(scene.k_gas, 0.8, 0.0, kc, 0.95, 0.7)
+                    scene2 = S.Scene(scene.name + "_2", scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
+                                     scene.k_gas, kc, ssa, asy)
+                    scene2.albedo, scene2.zenith_deg, scene2.azimuth_deg = scene.albedo, scene.zenith_deg, scene.azimuth_deg
+                    tr.upload_optics(*scene2.fields())
+                if second["kind"] in ("sun", "both"):
+                    if scene2 is scene:
+                        scene2 = S.Scene(scene.name + "_2", scene.itot, scene.jtot, scene.ktot, scene.dx, scene.dy, scene.dz,
+                                         *scene.fields())
+                    scene2.albedo, scene2.zenith_deg, scene2.azimuth_deg = second["albedo"], second["zenith"], second["azimuth"]
+                    tr.set_scene(scene2.zenith_deg, scene2.azimuth_deg, scene2.albedo)
+                if second["upload"]:                              # the counts so far leave the device and come back
+                    held = tr.tallies()
+                    tr.reset()
+                    tr.add_tallies(held)
+                tr.trace(second["seed"], pid0 + n, second["n"])
+                tr.synchronize()
         except Exception as exc:
             print("ERROR", desc, "seed:", seed, exc, flush=True)
             return 1
@@ -114,6 +152,11 @@ def main():
         want, wev = O.photon_oracle(scene, seed, pid0, n, fixed_dot=fixed_dot, supergrid=sg, launch_log2k=log2k,
                                     planar=planar, levels=levels, merge_tau=np.float32(tau_milli / 1000.0),
                                     launch_tile_log2=ltile)
+        if second is not None:                  # the oracle adds into the same arrays; a reset in between zeroes the
+            want, e2 = O.photon_oracle(scene2, second["seed"], pid0 + n, second["n"], tallies=want,    # event counters
+                                       fixed_dot=fixed_dot, supergrid=sg, launch_log2k=log2k, planar=planar, levels=levels,
+                                       merge_tau=np.float32(tau_milli / 1000.0), launch_tile_log2=ltile)
+            wev = e2 if second["upload"] else {k: wev[k] + e2[k] for k in wev}
         bad = [name for name in O.TALLY_NAMES if not np.array_equal(got[name], want[name])]
         if bad or (stats and gev != wev):
             print("MISMATCH", desc, "tallies:", bad, "events gpu/oracle:", gev, wev, flush=True)
