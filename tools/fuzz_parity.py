@@ -2,7 +2,11 @@
 """Randomised parity sweep on one GPU: random small scenes (ragged grids, clouds that touch the surface or the
 domain top, cloud-free and gas-free columns, a single slab) x random options (pool size, supervoxel size, region
 levels, launch order, planar scattering, fixed dot, chunk, launch threshold) x random photon ID ranges, the HIP
-kernels against oracle/photon_oracle.c, every tally and event counter bit for bit.
+kernels against oracle/photon_oracle.c, every tally and event counter bit for bit. Later case ranges add options
+without changing what earlier case numbers mean: launch sort and tiled launch order (all), kernels without event
+counters and several sort batches (from 300 000), grids of whole 32-column tiles (400 000), split calls through
+rt_trace_noalloc (500 000), grids of one to four cells per axis (700 000), any sun angle and a context used twice
+with a new sun or new optics (1 100 000).
 
 Test infrastructure like tests/ (it calls the oracle as the checker). Usage, on the GPU box:
     python tools/fuzz_parity.py [cases=200] [first_case=0]
