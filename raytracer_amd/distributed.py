@@ -85,7 +85,8 @@ class ShardedTracer:
     step's trace, and a step waits only for the all-reduce that used its buffer two steps earlier. With `wire32`
     the counts cross the wire as 32-bit words (narrow -> all-reduce -> widen); if any rank holds a count too large
     for that (the narrowing kernel checks on the device, the flag is summed with the data) result() repeats the
-    exchange on the 64-bit buffer, which the widening kernel then has left untouched."""
+    exchange on the 64-bit buffer, which the widening kernel then has left untouched. `reserve_lds` caps the pool
+    kernel at POOL_WAVES_BESIDE_A_COLLECTIVE waves per CU while overlapping (an experiment, see above: off)."""
 
     def __init__(self, tracer, device, group=None, overlap=None, wire32=True, force_collective=False,
                  reserve_lds=False):
