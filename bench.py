@@ -177,6 +177,14 @@ def main():
     # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a five-line version banner at
     # its first collective), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the
     # saved descriptor at the end.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become the launcher the contract describes (a child process; nothing here
+        # has touched the GPU yet), one rank per GPU, and pass its exit status on
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300),
+               os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)

@@ -49,3 +49,19 @@ def test_collective_path_keeps_stdout_clean():
     assert len(lines) == 1, r.stdout[:500]
     d = json.loads(lines[0])
     assert "RCCL all-reduce" in d["config"]["workload"] and d["value"] > 1e8
+
+
+def test_two_ranks_started_plainly_with_gpus_2():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run, as the driver would);
+    here both on the one GPU of the test box with the gloo stand-in for RCCL. Still ONE JSON line, from rank 0, with the
+    whole job's photons."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo",
+                        "--workload", "c1", "--photons-log2", "21", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["photons_per_gpu_per_step"] == 1 << 21
+    assert abs(d["value"] - 2 * (1 << 21) / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

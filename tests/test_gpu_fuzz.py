@@ -42,7 +42,7 @@ def test_random_scenes_and_options_bit_identical_to_oracle(rt, first, capsys):
 
 def test_random_driver_runs_bit_identical_to_oracle(rt, capsys):
     """A slice of tools/fuzz_drivers.py: the C++ driver raytracer_3d_io_gpu on random scenes with random --seed,
-    --launch, --launch-tile and --resume splits against the oracle (the tool was run over 3 250 cases)."""
+    --launch, --launch-tile and --resume splits against the oracle (the tool was run over 6 250 cases)."""
     import fuzz_drivers
     argv = sys.argv
     sys.argv = ["fuzz_drivers.py", "12", "1000"]
