@@ -131,7 +131,9 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    supervoxel size, and 1000)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
- *                    waiting lanes are served regardless (scheduling only: results do not change)
+ *                    waiting lanes are served regardless (scheduling only: results do not change; they steer the
+ *                    lane-resident kernel, option "pool" = 0 -- the pool kernel schedules by slot counts and has no
+ *                    scatter stage: its event round also turns the photon and takes its next step)
  *   "launch_log2k"   -1 (default): launch positions uniform over the domain top; k >= 0: stratified by
  *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
  *                    pass over the columns rotated by a per-pass random offset (stands in for the
@@ -263,8 +265,8 @@ int rt_get_events(rt_context* ctx, uint64_t out[RT_N_EVENTS]);
 
 /* Wave-scheduling statistics of "stats" launches since the last reset: rounds run and lanes
  * served per stage {T rounds, E rounds, S rounds, T lanes, E lanes, S lanes, slab rounds, slab lanes}
- * (T = traverse inside the grid, E = collision/surface event, S = new direction, slab = everything
- * outside the grid). Diagnostic only. */
+ * (T = traverse inside the grid, E = collision/surface event, S = new direction -- a stage of its own only in the
+ * lane-resident kernel, 0 for the pool kernel --, slab = everything outside the grid). Diagnostic only. */
 #define RT_N_SCHED 8
 int rt_get_sched_stats(rt_context* ctx, uint64_t out[RT_N_SCHED]);
 
