@@ -75,12 +75,13 @@ def test_rccl_world_size_one_overlapped_32bit_exchange(tmp_path):
     import torch.distributed as dist
     import raytracer_amd as rt
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                            pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))   # as bench.py does
     try:
         scene = rt.scenes.tiny()
         tr = rt.PhotonTracer.from_scene(scene, device=0)
-        st = rt.distributed.ShardedTracer(tr, "cuda:0", force_collective=True, overlap=True)
-        assert st.collective and st.overlap and st.wire32 and len(st.tallies) == 2
+        st = rt.distributed.ShardedTracer(tr, "cuda:0", force_collective=True, overlap=True, reserve_lds=True)
+        assert st.collective and st.overlap and st.wire32 and len(st.tallies) == 2     # (reserve_lds: the optional cap)
         got, handles = [], []
         for k, (seed, total, first) in enumerate(JOBS):
             handles.append(st.step(seed, total, first))
