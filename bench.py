@@ -214,10 +214,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            # RCCL over xGMI; its stream at high priority, so that the all-reduce kernel (which needs whole SIMDs'
-            # worth of registers, raytracer_amd/distributed.py) is placed ahead of the next trace's workgroups
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI (default stream priority: a
+            # high-priority RCCL stream bought nothing in tools/overlap_probe.py and hung a world-size-1 test once)
         else:
             dist.init_process_group("gloo")
 

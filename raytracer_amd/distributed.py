@@ -70,7 +70,8 @@ def trace_sharded(tracer, tally_tensor, seed: int, total_photons: int, first_pho
 # LDS AND 261-280 registers per lane (profiles/r2_rccl_kernel_resources.txt), so its 4-wave workgroup needs every SIMD
 # of a CU down to 3 pool waves (12 per CU), not 22. The cap cost the trace 4 % and bought nothing, so the overlap
 # rests on order instead: the all-reduce becomes ready when the narrowing kernel ends, the next trace only after the
-# 2 GiB tally memset that follows it in the stream (about 0.5 ms), and bench.py gives RCCL a high-priority stream.
+# 2 GiB tally memset that follows it in the stream (about 0.5 ms). RCCL's stream stays at default priority: a
+# high-priority one changed nothing in tools/overlap_probe.py and hung the world-size-1 RCCL test once.
 POOL_WAVES_BESIDE_A_COLLECTIVE = 22
 
 

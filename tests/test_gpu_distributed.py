@@ -75,8 +75,7 @@ def test_rccl_world_size_one_overlapped_32bit_exchange(tmp_path):
     import torch.distributed as dist
     import raytracer_amd as rt
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
-                            pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))   # as bench.py does
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         scene = rt.scenes.tiny()
         tr = rt.PhotonTracer.from_scene(scene, device=0)
