@@ -722,7 +722,8 @@ def test_launch_sort_at_full_size_is_identical_to_ascending_ids(rt):
     """The launch sort at BASELINE's size: 2^28 + 12345 photons with uniform launch positions through the
     1024x1024x128 grid in two sort batches, against the same IDs taken in ascending order (same majorant tables,
     chosen explicitly: the automatic ones depend on the option). Every ID exactly once <=> all seven tallies
-    bit-identical; toa_down (counted by the sort's own pass) sums to the photon count."""
+    bit-identical; toa_down (counted by the sort's own pass) sums to the photon count; and those tallies against
+    6*10^7 photons of oracle/cpu_ref.cpp (fixture cpu_ref_c4_6e7.npz) like the stratified run's."""
     scene = rt.scenes.cumulus_c4()
     n = (1 << 28) + 12345
     got = []
@@ -734,6 +735,9 @@ def test_launch_sort_at_full_size_is_identical_to_ascending_ids(rt):
         tr.close()
     assert int(got[0]["toa_down"].sum()) == n and rt.photon_balance(got[0]) == 0
     _assert_same(got[0], got[1])
+    # and the reference's own launch sampling on this grid against the reference side (the stratified order has
+    # test_c4_les_grid_2p30_photons_against_reference_restatement): toa_down is Poisson here, so all five 2-D tallies
+    _check_against_fixture(got[0], n, "cpu_ref_c4_6e7.npz", scene, {"blocks": TWO_D})
 
 
 @pytest.mark.parametrize("pool", [0, 128])
