@@ -1,6 +1,6 @@
 """Randomised parity on the GPU: a slice of tools/fuzz_parity.py (random ragged scenes x random options x random
 photon ID ranges; HIP kernels against oracle/photon_oracle.c, tallies and event counters bit for bit). The tool
-itself was run over 3 400 cases on the round-1 kernel and some 903 000 on round 2's ("Randomised
+itself was run over 3 400 cases on the round-1 kernel and some 975 000 on round 2's ("Randomised
 parity"); the suite keeps 200 of them, half from the ranges whose cases also draw the options added in round 2
 (launch sort, tiled launch order, counter-free kernels, several sort batches, 32-column tiles, split calls through
 rt_trace_noalloc; from case 1 100 000 any sun and surface, and a context used twice: a new sun or new optics, counts
