@@ -38,12 +38,15 @@ struct Config
     std::string indir = ".", outdir = ".";
     int exponent = -1;
     bool fixed_dot = false;
-    // --launch=auto (default) | K | uniform: stratified launch, 2^K consecutive photon IDs per column
-    // (the library's "launch_log2k"; stands in for the reference's scrambled-Sobol launch positions,
-    // raytracer_kernels.cu:239-253, 331). It samples the domain top evenly only over whole passes of
-    // ncol * 2^K photons per GPU; "auto" takes the largest K <= 5 (<= 8 on grids beyond the caches, where it also
-    // counts the columns in tiles of 32 x 32: --launch-tile=T, the library's "launch_tile_log2") for which the photon
-    // count allows that, else uniform random positions (which the library sorts by launch tile on the device).
+    // --launch=auto (default) | sobol | K | uniform (the library's "launch_log2k": -2, K >= 0, -1). sobol: photon ID n
+    // enters at point n of the two-dimensional Sobol sequence, digitally shifted by the seed -- the reference's own
+    // launch (scrambled Sobol32, raytracer_kernels.cu:239-253, 331) as a function of the ID, even for any photon
+    // count on any grid. K: stratified, 2^K consecutive photon IDs per column; it samples the domain top evenly only
+    // over whole passes of ncol * 2^K photons per GPU. "auto" takes the largest K <= 5 (<= 8 on grids beyond the
+    // caches, where it also counts the columns in tiles of 32 x 32: --launch-tile=T, the library's
+    // "launch_tile_log2") for which the photon count allows whole passes, else sobol -- e.g. always on the 240 x 240
+    // columns of raytracer_3d_io.cu:15-17. uniform: Philox positions (Poisson counts per column). Sobol and uniform
+    // launches are sorted by launch tile on the device.
     int launch_log2k = -1;
     bool launch_auto = true;
     int launch_tile_log2 = -1;      // stratified launch: columns counted in tiles of 2^T columns square; -1 = with auto
@@ -170,6 +173,7 @@ inline void parse_args(int argc, char** argv, Config& c)
             else if (key == "launch")
             {
                 if (val == "uniform") { c.launch_log2k = -1; c.launch_auto = false; }
+                else if (val == "sobol") { c.launch_log2k = -2; c.launch_auto = false; }
                 else if (val == "auto") c.launch_auto = true;
                 else { c.launch_log2k = std::stoi(val); c.launch_auto = false; }
             }
@@ -327,14 +331,14 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     // beyond the caches (packed cells > 256 MiB) whose sides are multiples of 32 the columns are counted in tiles of
     // 32 x 32 and K may go up to 8 (one tile's photons keep its cells in the XCD's L2: +6 % on 1024 x 1024 x 128),
     // smaller grids keep rows and K <= 5 (more photons per column at a time contend for the same tally words there).
-    // No K with whole passes: uniform positions, which the library sorts by launch tile on the device.
+    // No K with whole passes: the Sobol launch (-2), which the library sorts by launch tile on the device.
     const bool tiles_fit = c.itot % 32 == 0 && c.jtot % 32 == 0;
     const bool beyond_caches = 16ull * ncell > (256ull << 20);
     int launch_log2k = c.launch_log2k;
     int launch_tile_log2 = c.launch_tile_log2 >= 0 ? c.launch_tile_log2 : (beyond_caches && tiles_fit ? 5 : 0);
     if (c.launch_auto)
     {
-        launch_log2k = -1;
+        launch_log2k = -2;
         for (int k = (beyond_caches && launch_tile_log2 > 0 ? 8 : 5); k >= 0 && launch_log2k < 0; --k)
             if (n_photons % ((uint64_t)c.ngpus * (ncol << k)) == 0) launch_log2k = k;
     }

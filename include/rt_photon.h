@@ -134,10 +134,16 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    waiting lanes are served regardless (scheduling only: results do not change; they steer the
  *                    lane-resident kernel, option "pool" = 0 -- the pool kernel schedules by slot counts and has no
  *                    scatter stage: its event round also turns the photon and takes its next step)
- *   "launch_log2k"   -1 (default): launch positions uniform over the domain top; k >= 0: stratified by
- *                    column — 2^k consecutive photon IDs per column, columns in row-major order, every
- *                    pass over the columns rotated by a per-pass random offset (stands in for the
- *                    reference's scrambled-Sobol launch, raytracer_kernels.cu:239-253, 331)
+ *   "launch_log2k"   -1 (default): launch positions uniform over the domain top (two Philox draws);
+ *                    -2 (also option "launch_sobol" = 1): photon ID n enters at point (n mod 2^32) of the
+ *                    two-dimensional Sobol sequence, digitally shifted by a per-seed, per-2^32-ID-block draw -- the
+ *                    reference's launch (scrambled Sobol32 dimensions 0 and 1 at offset tid * photons_per_thread,
+ *                    raytracer_kernels.cu:239-253, 331, tables raytracer_3d.cu:135-145) as a pure function of the
+ *                    photon ID: any aligned block of 2^m consecutive IDs puts exactly one photon into every
+ *                    elementary interval 2^-a x 2^-(m-a) of the domain top, on any grid and for any photon count;
+ *                    k >= 0: stratified by column — 2^k consecutive photon IDs per column, columns in row-major
+ *                    order, every pass over the columns rotated by a per-pass random offset (even only over whole
+ *                    passes of ncol * 2^k IDs)
  *   "launch_tile_log2" stratified launch: T > 0 counts the columns tile by tile (tiles of 2^T x 2^T columns, row-major
  *                    inside, tiles row by row; itot and jtot must be multiples of 2^T, else rt_trace refuses) instead of
  *                    row by row (0, default), so that the photons in flight together share a neighbourhood in both
@@ -281,6 +287,12 @@ int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint3
 /* Test hook: evaluates the device math (0 = log, 1 = x^(-1/3), 2 = sin(2*pi*x), 3 = cos(2*pi*x), 4 = the
  * Rayleigh cosine of a uniform draw, 5 = the Henyey-Greenstein cosine at g = 0.85) on n host floats. */
 int rt_selftest_math(int device_id, int which, const float* in, size_t n, float* out);
+
+/* Test hook: where photons pid_begin .. pid_begin + n - 1 enter the domain top under the context's launch option
+ * (uniform or Sobol; the range must not cross a multiple of 2^32): xy[2n] positions in metres and, if words is not
+ * NULL, the two 32-bit words they were scaled from (Philox draws, or the digitally shifted Sobol point -- what
+ * curand(&state_x), curand(&state_y) return in raytracer_kernels.cu:248-249). */
+int rt_selftest_launch(rt_context* ctx, uint64_t seed, uint64_t pid_begin, size_t n, float* xy, uint32_t* words);
 
 /* Test hook: the device's short sqrt (which = 0) or reciprocal (which = 1) against the compiler's IEEE
  * sqrtf / division on the `count` consecutive float bit patterns from first_bits on; out[0] = number of

@@ -83,6 +83,28 @@ static inline void draw(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag
 /* top 24 bits -> [0,1), every value exactly representable */
 static inline float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 
+/* The two 32-bit words a photon's launch position is scaled from under the Sobol launch (what curand(&state_x),
+ * curand(&state_y) return in raytracer_kernels.cu:248-249): point (pid mod 2^32), in natural index order, of the
+ * two-dimensional Sobol sequence with the Joe-Kuo direction numbers of dimensions 0 and 1 (the tables the reference
+ * copies from cuRAND, raytracer_3d.cu:135-140), by the textbook recurrence: dimension 0 has v_k = 2^(31-k) (the
+ * radical inverse), dimension 1 v_0 = 2^31, v_k = v_(k-1) ^ (v_(k-1) >> 1). shifted != 0: XORed with the digital
+ * shift of the photon's block of 2^32 IDs, a Philox draw keyed on the seed (cuRAND's scramble constants,
+ * raytracer_3d.cu:141-145, enter its state by the same XOR). tests/test_oracle_photon.py pins the unshifted words
+ * to scipy.stats.qmc.Sobol (same direction numbers, Gray-code order). */
+void oracle_sobol_words(uint64_t seed, uint64_t pid, int shifted, uint32_t out[2])
+{
+    uint32_t s0 = 0u, s1 = 0u, v0 = 0x80000000u, v1 = 0x80000000u;
+    if (shifted)
+    {
+        uint32_t w[4];
+        draw(seed, pid >> 32, 0xFFFFFFFFu, 2u, w);
+        s0 = w[0]; s1 = w[1];
+    }
+    for (uint32_t n = (uint32_t)pid; n; n >>= 1, v0 >>= 1, v1 ^= v1 >> 1)
+        if (n & 1u) { s0 ^= v0; s1 ^= v1; }
+    out[0] = s0; out[1] = s1;
+}
+
 /* ---------------------------------------------------------------- deterministic math ----- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -211,7 +233,8 @@ typedef struct
     float zenith_rad, azimuth_rad, albedo;
     int fixed_dot; /* 0 = dot() as the reference writes it (v1.z*v1.z), 1 = v1.z*v2.z */
     int sx, sy, sz; /* supervoxel size in cells for the majorant grid of the cloud slab; 0 = none */
-    int launch_log2k; /* < 0: launch positions uniform over the domain (one Philox draw per axis);
+    int launch_log2k; /* -1: launch positions uniform over the domain (one Philox draw per axis); -2: the Sobol
+                         sequence indexed by the photon ID, digitally shifted (the reference's launch);
                          >= 0: stratified by column, 2^launch_log2k consecutive photon IDs per column */
     int planar; /* 1: the scattering rule of the reference's 2D tracer — directions stay in the x-z plane:
                    a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
@@ -475,7 +498,19 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
     /* launch, raytracer_kernels.cu:180-208 */
     draw(seed, pid, nev++, 0u, w);
     float x, y;
-    if (sc->launch_log2k < 0)
+    if (sc->launch_log2k == -2)
+    {
+        /* Sobol launch: the reference's own (raytracer_kernels.cu:239-253, 331: scrambled Sobol32 dimensions 0 and
+         * 1, tables raytracer_3d.cu:135-145, positions scaled as :195-196), as a function of the photon ID: point
+         * (ID mod 2^32) of the sequence by the textbook recurrence -- dimension 0 the radical inverse (direction
+         * numbers 2^(31-k)), dimension 1 v_0 = 2^31, v_k = v_(k-1) ^ (v_(k-1) >> 1) -- XORed with a digital shift
+         * drawn per seed and per block of 2^32 IDs (counter words no photon's own stream uses). */
+        uint32_t s[2];
+        oracle_sobol_words(seed, pid, 1, s);
+        x = xs * u01(s[0]);
+        y = ys * u01(s[1]);
+    }
+    else if (sc->launch_log2k < 0)
     {
         x = xs * u01(w[0]);
         y = ys * u01(w[1]);

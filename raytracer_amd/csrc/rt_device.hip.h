@@ -58,6 +58,28 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 // top 24 bits -> [0,1) on the 2^-24 lattice (exact)
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 
+// Point n of the two-dimensional Sobol sequence -- dimensions 0 and 1 of the Joe-Kuo direction numbers the
+// reference hands to cuRAND (raytracer_3d.cu:135-145), a (0,2)-sequence in base 2 -- as a function of the index,
+// no state and no table (the reference walks two curandStateScrambledSobol32 generators from offset
+// tid * photons_per_thread, raytracer_kernels.cu:239-253, 331). Dimension 0 is the bit reversal of n (direction
+// numbers 2^(31-k): v_bfrev_b32). Dimension 1 has the direction numbers v_k = v_(k-1) ^ (v_(k-1) >> 1), v_0 = 2^31,
+// i.e. the Pascal matrix mod 2: output bit 31-j is the XOR of the index bits k whose binary digits contain those of
+// j (Lucas), which on the bit-reversed index is a sum over subsets -- five shift-and-XOR steps. sx, sy: the digital
+// shift (cuRAND's "scramble constants" are XORed into the state the same way); a digital shift keeps every
+// elementary-interval property of the sequence.
+__device__ __forceinline__ void sobol_2d(uint32_t n, uint32_t sx, uint32_t sy, uint32_t& x0, uint32_t& x1)
+{
+    const uint32_t r = __builtin_bitreverse32(n);
+    uint32_t y = r;
+    y ^= (y << 1) & 0xAAAAAAAAu;
+    y ^= (y << 2) & 0xCCCCCCCCu;
+    y ^= (y << 4) & 0xF0F0F0F0u;
+    y ^= (y << 8) & 0xFF00FF00u;
+    y ^= (y << 16) & 0xFFFF0000u;
+    x0 = r ^ sx;
+    x1 = y ^ sy;
+}
+
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // natural log of a positive normal float: mantissa to [sqrt(1/2), sqrt(2)), degree-9 polynomial

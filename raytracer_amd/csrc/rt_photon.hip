@@ -82,6 +82,9 @@ constexpr int kEventWords = kCursorWord + kXcds * kCursorStride;
 constexpr int kScratchWords = 256;
 constexpr int kScratchColdWord = kXcds * kCursorStride;
 constexpr int kMaxDevices = 64;
+// values of "launch_log2k" below zero: where a photon enters the domain top as a function of its ID
+constexpr int kLaunchUniform = -1;    // two Philox draws (the first block of the photon's stream)
+constexpr int kLaunchSobol = -2;      // point (ID mod 2^32) of the 2-D Sobol sequence, digitally shifted per 2^32-ID block
 
 // ------------------------------------------------------------------------------------------
 // Layout of the packed cell records in HBM (internal: tallies and every interface keep [k][j][i]). RT_BRICK = 0
@@ -143,6 +146,7 @@ struct TraceArgs
     float dx, dy;
     uint32_t div_itot_mul, div_itot_shift;    // c / launch_div == (c * mul) >> shift for c < 2^31
     uint32_t launch_div, launch_tile_log2;    // launch_div = itot, or the tiles per row of a tiled launch order
+    uint32_t sob_x, sob_y;                    // Sobol launch (launch_log2k == kLaunchSobol): digital shift of the launch's 2^32-ID block
 };
 
 // Kernel arguments of the pool tracer: only what the traverse step -- the traverse stage's, and the one at the end
@@ -190,6 +194,7 @@ struct ColdBlock
     int nslab;
     const uint32_t* sorted;       // launch sort: the launch's IDs (relative to pid_begin) in the order they are taken; or null
     uint32_t toa_done;            // launch sort: toa_down of this launch is already counted (rt_sort_toa_kernel)
+    uint32_t sob_x, sob_y;        // Sobol launch: digital shift of this launch's 2^32-ID block
 };
 
 // The cold block through the constant address space: its contents do not change while the tracer runs (the kernel
@@ -435,7 +440,16 @@ rt_trace_kernel(const TraceArgs a)
                 if (state == ST_LAUNCH)
                 {
                     // launch at the top of the domain, raytracer_kernels.cu:180-208
-                    if (a.launch_log2k < 0)
+                    if (a.launch_log2k == kLaunchSobol)
+                    {
+                        // point pid_lo of the Sobol sequence (raytracer_kernels.cu:195-196 scale the two 32-bit
+                        // words by the domain size the same way)
+                        uint32_t s0, s1;
+                        sobol_2d(pid_lo, a.sob_x, a.sob_y, s0, s1);
+                        x = a.xs * u01(s0);
+                        y = a.ys * u01(s1);
+                    }
+                    else if (a.launch_log2k < 0)
                     {
                         x = a.xs * u01(w.x);
                         y = a.ys * u01(w.y);
@@ -1286,7 +1300,14 @@ rt_trace_pool_kernel(const PoolArgs a)
                 tau_new = tau_new > 0.0f ? tau_new : 0.0f;
                 const int log2k = cb->launch_log2k;
                 float x, y;
-                if (log2k < 0)
+                if (log2k == kLaunchSobol)
+                {
+                    uint32_t s0, s1;
+                    sobol_2d(pid_lo, cb->sob_x, cb->sob_y, s0, s1);
+                    x = k->xs * u01(s0);
+                    y = k->ys * u01(s1);
+                }
+                else if (log2k < 0)
                 {
                     x = k->xs * u01(w.x);
                     y = k->ys * u01(w.y);
@@ -1518,14 +1539,23 @@ struct SortArgs
     float xs, ys, inv_dx, inv_dy;
     unsigned long long* toa_down; // pass 5
     uint32_t nslices;             // pass 5: workgroups per tile
+    int sobol;                    // launch positions from the Sobol sequence (no Philox block needed to find a tile)
+    uint32_t sob_x, sob_y;
 };
 
-// launch column of photon `pid`: the launch stage's own arithmetic (uniform positions)
+// launch column of photon `pid`: the launch stage's own arithmetic (uniform or Sobol positions)
 __device__ __forceinline__ void launch_ij(const SortArgs& s, uint64_t pid, uint32_t key0, uint32_t key1, uint32_t& i, uint32_t& j)
 {
-    const rt::u32x4 w = rt::philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), 0u, 0u, key0, key1);
-    i = (uint32_t)rt::cell_of(s.xs * rt::u01(w.x), s.inv_dx, s.itot);
-    j = (uint32_t)rt::cell_of(s.ys * rt::u01(w.y), s.inv_dy, s.jtot);
+    uint32_t wx, wy;
+    if (s.sobol)
+        rt::sobol_2d((uint32_t)pid, s.sob_x, s.sob_y, wx, wy);
+    else
+    {
+        const rt::u32x4 w = rt::philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), 0u, 0u, key0, key1);
+        wx = w.x; wy = w.y;
+    }
+    i = (uint32_t)rt::cell_of(s.xs * rt::u01(wx), s.inv_dx, s.itot);
+    j = (uint32_t)rt::cell_of(s.ys * rt::u01(wy), s.inv_dy, s.jtot);
 }
 
 __device__ __forceinline__ uint32_t launch_tile(const SortArgs& s, uint64_t pid, uint32_t key0, uint32_t key1)
@@ -1806,6 +1836,27 @@ __global__ void rt_selftest_math_kernel(int which, const float* in, size_t n, fl
         }
     }
 }
+// launch positions of n consecutive photon IDs (uniform or Sobol), with the tracer's own arithmetic
+__global__ void rt_selftest_launch_kernel(int sobol, uint32_t k0, uint32_t k1, uint32_t sob_x, uint32_t sob_y,
+                                          unsigned long long pid_begin, size_t n, float xs, float ys, float* xy, uint32_t* words)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    const unsigned long long pid = pid_begin + t;
+    uint32_t wx, wy;
+    if (sobol)
+        rt::sobol_2d((uint32_t)pid, sob_x, sob_y, wx, wy);
+    else
+    {
+        const rt::u32x4 w = rt::philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), 0u, 0u, k0, k1);
+        wx = w.x; wy = w.y;
+    }
+    xy[2 * t] = xs * rt::u01(wx);
+    xy[2 * t + 1] = ys * rt::u01(wy);
+    if (words) { words[2 * t] = wx; words[2 * t + 1] = wy; }
+}
+
 // rt_sqrt / rt_rcp against the compiler's IEEE sqrtf / division over a range of bit patterns
 __global__ void rt_selftest_exact_kernel(int which, uint32_t first, unsigned long long count, unsigned long long* out)
 {
@@ -2270,6 +2321,33 @@ int allreduce_impl(rt_context* const ctx[], int n)
     return RT_OK;
 }
 
+// Philox4x32-10 on the host (the device's rt::philox4x32_10, word for word) for the few values a launch needs
+// ahead of its kernels.
+void philox_host(const uint32_t ctr[4], uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    for (int round = 0; round < 10; ++round)
+    {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Digital shift of the Sobol launch for the 2^32 photon IDs of `block` (= ID >> 32): the scramble constants of
+// raytracer_3d.cu:141-145, here a Philox draw keyed on the seed and the block (counter words 2 and 3 are values
+// no photon's stream uses: event index 2^32 - 1, tag 2), so every block and every seed is an independent
+// randomisation of the sequence. The CPU checker draws the same block.
+void sobol_shift(uint64_t seed, uint64_t block, uint32_t& sx, uint32_t& sy)
+{
+    const uint32_t ctr[4] = {(uint32_t)block, (uint32_t)(block >> 32), 0xFFFFFFFFu, 2u};
+    uint32_t w[4];
+    philox_host(ctr, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    sx = w[0]; sy = w[1];
+}
+
 // Launches the tracer for photon IDs [pid_begin, pid_begin + count). `cursor` / `cold`: the device words the pool
 // kernel takes its photon-ID cursors and cold block from -- the context's own allocation (rt_trace) or the static
 // scratch (rt_trace_noalloc, which must not allocate: it refuses instead of building majorants).
@@ -2323,6 +2401,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         div_mul = (uint32_t)(((1ull << div_shift) / (uint64_t)launch_div) + 1ull);
     }
     const bool gridded = sl.gslab >= 0;
+    const bool sobol = c->launch_log2k == kLaunchSobol;
 
     // Launch sort (rt_sort_count_kernel): uniform launch positions, pool kernel; by default from 2^19 photons per call
     // (below that the five small kernels cost what the order gains). The IDs go through in batches of
@@ -2410,9 +2489,19 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
             so.nslices = (uint32_t)((sort_blocks(c) + so.ntiles - 1) / so.ntiles);
         }
         const bool toa_pass = sorted && so.tile_shift <= 6u;      // the tile's columns fit the pass's LDS histogram
-        for (uint64_t done = 0; done < count; done += batch)
+        // Sobol launch: a launch stays inside one block of 2^32 IDs (the sequence's index is the low word of the
+        // ID, its digital shift belongs to the block), so a range that crosses a multiple of 2^32 is cut there
+        for (uint64_t done = 0, nb = 0; done < count; done += nb)
         {
-            const uint64_t nb = count - done < batch ? count - done : batch, b0 = pid_begin + done;
+            const uint64_t b0 = pid_begin + done;
+            nb = count - done < batch ? count - done : batch;
+            if (sobol)
+            {
+                const uint64_t to_block_end = (((b0 >> 32) + 1ull) << 32) - b0;
+                if (nb > to_block_end) nb = to_block_end;
+                sobol_shift(seed, b0 >> 32, cb.sob_x, cb.sob_y);
+                so.sobol = 1; so.sob_x = cb.sob_x; so.sob_y = cb.sob_y;
+            }
             // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
             // every resident wave still finds work
             uint32_t chunk = (uint32_t)c->chunk;
@@ -2520,19 +2609,33 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         a.div_itot_mul = div_mul; a.div_itot_shift = div_shift;
         a.launch_div = launch_div; a.launch_tile_log2 = tile_log2;
 
-        uint64_t blocks = (count + kBlock - 1) / kBlock;
-        const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
-        if (blocks > cap) blocks = cap;
-        const dim3 grid((unsigned)blocks), block(kBlock);
-        if (c->fixed_dot)
+        a.sob_x = 0u; a.sob_y = 0u;
+
+        // (Sobol launch: one launch per block of 2^32 IDs, as in the pool path)
+        for (uint64_t p0 = pid_begin, p1 = 0; p0 < pid_begin + count; p0 = p1)
         {
-            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
-            else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
-        }
-        else
-        {
-            if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
-            else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+            p1 = pid_begin + count;
+            if (sobol)
+            {
+                const uint64_t block_end = ((p0 >> 32) + 1ull) << 32;
+                if (block_end != 0ull && block_end < p1) p1 = block_end;
+                sobol_shift(seed, p0 >> 32, a.sob_x, a.sob_y);
+            }
+            a.pid_begin = p0; a.pid_end = p1;
+            uint64_t blocks = (p1 - p0 + kBlock - 1) / kBlock;
+            const uint64_t cap = (uint64_t)c->cu_count * c->blocks_per_cu;
+            if (blocks > cap) blocks = cap;
+            const dim3 grid((unsigned)blocks), block(kBlock);
+            if (c->fixed_dot)
+            {
+                if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<true, true>), grid, block, 0, c->stream, a);
+                else hipLaunchKernelGGL((rt_trace_kernel<true, false>), grid, block, 0, c->stream, a);
+            }
+            else
+            {
+                if (c->stats) hipLaunchKernelGGL((rt_trace_kernel<false, true>), grid, block, 0, c->stream, a);
+                else hipLaunchKernelGGL((rt_trace_kernel<false, false>), grid, block, 0, c->stream, a);
+            }
         }
     }
     RT_HIP(hipGetLastError());
@@ -2727,8 +2830,16 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "launch_log2k"))
     {
-        if (value < -1 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-1,20]", value);
+        if (value < -2 || value > 20) return fail(RT_ERR_ARG, "rt_set_option: launch_log2k %lld outside [-2,20]", value);
         c->launch_log2k = (int)value;
+        if (wants_fine(c) != c->built_fine) c->maj_dirty = true;
+    }
+    else if (!strcmp(name, "launch_sobol"))
+    {
+        // by name: 1 = the Sobol launch (launch_log2k = -2), 0 = back to uniform positions if it was on
+        if (value != 0 && value != 1) return fail(RT_ERR_ARG, "rt_set_option: launch_sobol %lld not 0 or 1", value);
+        if (value == 1) c->launch_log2k = kLaunchSobol;
+        else if (c->launch_log2k == kLaunchSobol) c->launch_log2k = kLaunchUniform;
         if (wants_fine(c) != c->built_fine) c->maj_dirty = true;
     }
     else if (!strcmp(name, "levels"))
@@ -3006,6 +3117,30 @@ int rt_selftest_philox(int device_id, const uint32_t* ctr, size_t n, const uint3
     hipLaunchKernelGGL(rt_selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in.p, n, key[0], key[1], d_out.p);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpy(out, d_out.p, 16 * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_selftest_launch(rt_context* c, uint64_t seed, uint64_t pid_begin, size_t n, float* xy, uint32_t* words)
+{
+    if (!c || !xy) return fail(RT_ERR_ARG, "rt_selftest_launch: null argument");
+    if (c->launch_log2k >= 0) return fail(RT_ERR_ARG, "rt_selftest_launch: uniform or Sobol launch only");
+    if (n == 0) return RT_OK;
+    if (pid_begin + n < pid_begin || ((pid_begin + n - 1) >> 32) != (pid_begin >> 32))
+        return fail(RT_ERR_ARG, "rt_selftest_launch: the range crosses a multiple of 2^32");
+    RT_HIP(hipSetDevice(c->device));
+    HookBuffer<float> d_xy;
+    HookBuffer<uint32_t> d_w;
+    RT_HIP(hipMalloc(&d_xy.p, 8 * n));
+    if (words) RT_HIP(hipMalloc(&d_w.p, 8 * n));
+    uint32_t sx = 0, sy = 0;
+    const int sobol = c->launch_log2k == kLaunchSobol;
+    if (sobol) sobol_shift(seed, pid_begin >> 32, sx, sy);
+    hipLaunchKernelGGL(rt_selftest_launch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, sobol, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sx, sy, (unsigned long long)pid_begin, n, (float)c->itot * c->dx,
+                       (float)c->jtot * c->dy, d_xy.p, d_w.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpy(xy, d_xy.p, 8 * n, hipMemcpyDeviceToHost));
+    if (words) RT_HIP(hipMemcpy(words, d_w.p, 8 * n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

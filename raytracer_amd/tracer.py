@@ -25,6 +25,9 @@ EVENT_NAMES = ("steps", "collision_tests", "real", "scatter", "cloud_scatter", "
                "absorb", "transition", "abort")
 
 
+LAUNCH_UNIFORM, LAUNCH_SOBOL = -1, -2      # values of option "launch_log2k" below zero (include/rt_photon.h)
+
+
 class RtError(RuntimeError):
     pass
 
@@ -91,6 +94,7 @@ def load_library():
         "rt_selftest_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "rt_selftest_math": (C.c_int, [C.c_int, C.c_int, f32p, C.c_size_t, f32p]),
         "rt_selftest_exact": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint64, u64p]),
+        "rt_selftest_launch": (C.c_int, [vp, u64, u64, C.c_size_t, f32p, C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -259,6 +263,15 @@ class PhotonTracer:
         _check(self.lib.rt_get_region_levels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n))
         return out
 
+    def launch_positions(self, seed, photon_id_begin, n):
+        """Where photons [begin, begin + n) enter the domain top under the current launch option (uniform or Sobol):
+        (xy float32 [n, 2] in metres, words uint32 [n, 2] they were scaled from). Test hook."""
+        xy = np.zeros((int(n), 2), dtype=np.float32)
+        words = np.zeros((int(n), 2), dtype=np.uint32)
+        _check(self.lib.rt_selftest_launch(self._h, int(seed), int(photon_id_begin), int(n), _f32p(xy),
+                                           words.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return xy, words
+
     def set_supergrid(self, sx, sy, sz):
         """Supervoxel size in cells of the majorant grid over the cloud slab; (0,0,0) disables it."""
         for axis, v in zip("xyz", (sx, sy, sz)):
@@ -297,14 +310,16 @@ def choose_launch_order(itot, jtot, ktot, photons_per_call, ngpus=1):
     of 32 the columns are counted in tiles of 32 x 32 and k may go up to 8: a tile's 2^(10+k) photons keep its
     cells in one XCD's L2 (1024 x 1024 x 128: a third of the memory traffic, +6 % photons/s). Smaller grids keep
     rows and k <= 5 (more photons per column at a time contend for the same tally words there). No k with whole
-    passes: (-1, 0), uniform launch positions, which the library sorts by launch tile on the device."""
+    passes (any photon count on a grid whose column count is not a power of two, e.g. the 240 x 240 columns of
+    raytracer_3d_io.cu:15-17): (LAUNCH_SOBOL, 0) -- the Sobol sequence indexed by the photon ID, even for every
+    count, which the library sorts by launch tile on the device."""
     ncol = itot * jtot
     beyond_caches = 16 * ncol * ktot > (256 << 20)
     tile = 5 if beyond_caches and itot % 32 == 0 and jtot % 32 == 0 else 0
     for k in range(8 if tile else 5, -1, -1):
         if photons_per_call % (ngpus * (ncol << k)) == 0:
             return k, tile
-    return -1, 0
+    return LAUNCH_SOBOL, 0
 
 
 def split_tally_words(words, itot, jtot, ktot):

@@ -67,6 +67,8 @@ def lib():
         _lib.oracle_free_slabs.argtypes = [C.POINTER(OracleSlabs)]
         _lib.oracle_philox4x32_10.restype = None
         _lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        _lib.oracle_sobol_words.restype = None
+        _lib.oracle_sobol_words.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
         _lib.oracle_logf.restype = C.c_float
         _lib.oracle_logf.argtypes = [C.c_float]
         _lib.oracle_inv_cbrtf.restype = C.c_float
@@ -139,6 +141,17 @@ def photon_oracle(scene, seed, pid_begin, count, nthreads=0, tallies=None, fixed
     if rc != 0:
         raise RuntimeError(f"photon_oracle_trace failed: {rc}")
     return t, dict(zip(EVENT_NAMES, (int(v) for v in ev)))
+
+
+def sobol_words(seed, pids, shifted=True):
+    """The oracle's Sobol launch words of the given photon IDs: uint32 [n, 2]."""
+    out = np.zeros((len(pids), 2), dtype=np.uint32)
+    w = (C.c_uint32 * 2)()
+    fn = lib().oracle_sobol_words
+    for r, pid in enumerate(pids):
+        fn(int(seed), int(pid), int(shifted), w)
+        out[r] = (w[0], w[1])
+    return out
 
 
 def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID, levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleSlabs:

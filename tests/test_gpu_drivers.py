@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GPU = os.path.join(ROOT, "drivers", "raytracer_3d_gpu")
 IO = os.path.join(ROOT, "drivers", "raytracer_3d_io_gpu")
 GPU2D = os.path.join(ROOT, "drivers", "raytracer_gpu")
+# --launch=auto when the photon count is no whole number of passes over the columns: the Sobol launch (f1)
+SOBOL = -2
 
 
 def _read(d, sc):
@@ -59,15 +61,17 @@ def test_file_input_driver_and_zenith_sweep(tmp_path):
     dims = [f"--itot={sc.itot}", f"--jtot={sc.jtot}", f"--ktot={sc.ktot}", f"--dx={sc.dx}", f"--dy={sc.dy}", f"--dz={sc.dz}"]
     r = subprocess.run([IO, "16", "--seed=3", *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    want, _ = O.photon_oracle(sc, 3, 0, 1 << 16)
+    want, _ = O.photon_oracle(sc, 3, 0, 1 << 16, launch_log2k=SOBOL)     # 192 columns: no whole pass, so auto = Sobol
     got = _read(tmp_path, sc)
+    ck = dict(l.split(" = ") for l in open(tmp_path / "checkpoint").read().splitlines() if " = " in l)
+    assert ck["launch_log2k"] == "-2"
     for n in TALLY_NAMES:
         assert np.array_equal(got[n], want[n]), n
     r = subprocess.run([IO, "15", "--zenith=0,30,60", *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     for zen in (0, 30, 60):
         sc.zenith_deg = float(zen)
-        want, _ = O.photon_oracle(sc, 0, 0, 1 << 15)
+        want, _ = O.photon_oracle(sc, 0, 0, 1 << 15, launch_log2k=SOBOL)
         got = _read(tmp_path / f"zenith_{zen:02d}", sc)
         for n in TALLY_NAMES:
             assert np.array_equal(got[n], want[n]), (zen, n)
@@ -76,7 +80,7 @@ def test_file_input_driver_and_zenith_sweep(tmp_path):
 def test_resume_continues_the_photon_sequence(tmp_path):
     """f2 (the restart raytracer_3d.cu:89, 98-104 prepares for): two runs of 2^17 photons, the second with --resume,
     leave exactly the files of one run of 2^18 -- tallies and checkpoint -- for the built-in scene driver (stratified
-    launch, K fixed by the first run) and for the file driver (uniform launch, two GPUs' worth of shards)."""
+    launch, K fixed by the first run) and for the file driver (Sobol launch, chosen by auto and kept by --resume)."""
     one, two = tmp_path / "one", tmp_path / "two"
     one.mkdir(); two.mkdir()
     sc = scenes.block_cloud()
@@ -104,14 +108,14 @@ def test_resume_continues_the_photon_sequence(tmp_path):
         assert r.returncode == 1 and msg in r.stderr, (bad, r.stderr)
     r = subprocess.run([GPU, "17", "--resume"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "checkpoint" in r.stderr
-    # a third leg on the file driver, uniform launch, three legs of 2^15 == one call of 3 * 2^15 photon ids
+    # a third leg on the file driver, Sobol launch, three legs of 2^15 == one call of 3 * 2^15 photon ids
     tiny = scenes.tiny()
     d = tmp_path / "io"
     tiny.write(str(d))
     for leg in range(3):
         r = subprocess.run([IO, "15", "--seed=4"] + (["--resume"] if leg else []), cwd=d, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
-    want, _ = O.photon_oracle(tiny, 4, 0, 3 << 15)
+    want, _ = O.photon_oracle(tiny, 4, 0, 3 << 15, launch_log2k=SOBOL)
     got = _read(d, tiny)
     for n in TALLY_NAMES:
         assert np.array_equal(got[n], want[n]), n
@@ -126,7 +130,7 @@ def test_zenith_and_azimuth_sweep(tmp_path):
     for zen in (20, 55):
         for azi in (0, 135):
             sc.zenith_deg, sc.azimuth_deg = float(zen), float(azi)
-            want, _ = O.photon_oracle(sc, 0, 0, 1 << 15)
+            want, _ = O.photon_oracle(sc, 0, 0, 1 << 15, launch_log2k=SOBOL)
             got = _read(tmp_path / f"zenith_{zen:02d}_azimuth_{azi:03d}", sc)
             for n in TALLY_NAMES:
                 assert np.array_equal(got[n], want[n]), (zen, azi, n)
@@ -138,7 +142,8 @@ def test_zenith_and_azimuth_sweep(tmp_path):
 def test_io_driver_at_its_default_grid_with_a_zenith_sweep(tmp_path):
     """BASELINE config 5 at the grid raytracer_3d_io.cu:11-17 compiles in (240 x 240 x 284 cells of 100/100/30 m): no
     dimension options, no sidecar, four headerless float32 files of 65 MB each, two solar zenith angles with the
-    full 3D absorption output per run; bit-identical to the oracle."""
+    full 3D absorption output per run; bit-identical to the oracle. 57600 columns admit no whole pass for 2^20
+    photons: --launch=auto (the default) takes the Sobol launch here, and toa_down is far more even than Poisson."""
     sc = scenes.cumulus(240, 240, 284, 100.0, 100.0, 30.0, n_clouds=60, seed=7, z_base=900.0, z_top=3000.0,
                         name="io_default_grid")
     sc.write(str(tmp_path), sidecar=False)
@@ -146,22 +151,28 @@ def test_io_driver_at_its_default_grid_with_a_zenith_sweep(tmp_path):
     assert r.returncode == 0, r.stderr
     for zen in (20, 65):
         sc.zenith_deg = float(zen)
-        want, _ = O.photon_oracle(sc, 6, 0, 1 << 20)
+        want, _ = O.photon_oracle(sc, 6, 0, 1 << 20, launch_log2k=SOBOL)
         got = _read(tmp_path / f"zenith_{zen:02d}", sc)
         for n in TALLY_NAMES:
             assert np.array_equal(got[n], want[n]), (zen, n)
+        td = got["toa_down"].astype(np.float64)
+        assert td.var() < 0.2 * td.mean(), (td.var(), td.mean())      # 18.2 photons per column on average
+        ck = dict(l.split(" = ") for l in open(tmp_path / f"zenith_{zen:02d}" / "checkpoint").read().splitlines() if " = " in l)
+        assert ck["launch_log2k"] == "-2"
         assert O.balance(got) == 0 and got["atmos_direct"].shape == (284, 240, 240)
 
 
 def test_stratified_launch_option_of_the_drivers(tmp_path):
-    """--launch=auto picks the largest K <= 5 with whole passes of ncol * 2^K photons; --launch=K is explicit."""
+    """--launch=auto picks the largest K <= 5 with whole passes of ncol * 2^K photons, else the Sobol launch;
+    --launch=K, --launch=sobol and --launch=uniform are explicit."""
     sc = scenes.tiny()
     sc.write(str(tmp_path))
     ncol = sc.itot * sc.jtot
     dims = [f"--itot={sc.itot}", f"--jtot={sc.jtot}", f"--ktot={sc.ktot}", f"--dx={sc.dx}", f"--dy={sc.dy}", f"--dz={sc.dz}"]
     n = 1 << 16
-    k_auto = max((k for k in range(6) if n % (ncol << k) == 0), default=-1)
-    for arg, k in (("--launch=auto", k_auto), ("--launch=2", 2), ("--launch=uniform", -1)):
+    k_auto = max((k for k in range(6) if n % (ncol << k) == 0), default=SOBOL)
+    assert k_auto == SOBOL
+    for arg, k in (("--launch=auto", k_auto), ("--launch=2", 2), ("--launch=uniform", -1), ("--launch=sobol", SOBOL)):
         r = subprocess.run([IO, "16", "--seed=5", arg, *dims], cwd=tmp_path, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         want, _ = O.photon_oracle(sc, 5, 0, n, launch_log2k=k)
@@ -214,7 +225,7 @@ def test_io_driver_reads_the_sidecar_header(tmp_path):
     sc.write(str(tmp_path), dtype=np.float64)
     r = subprocess.run([IO, "16", "--seed=8"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    want, _ = O.photon_oracle(sc, 8, 0, 1 << 16)
+    want, _ = O.photon_oracle(sc, 8, 0, 1 << 16, launch_log2k=SOBOL)
     got = _read(tmp_path, sc)
     for n in TALLY_NAMES:
         assert np.array_equal(got[n], want[n]), n

@@ -25,7 +25,7 @@ def rt():
     return raytracer_amd
 
 
-@pytest.mark.parametrize("first", [0, 1000, 2000, 3000, 300000, 400000, 500000, 543210, 700000, 1100000])
+@pytest.mark.parametrize("first", [0, 1000, 2000, 3000, 300000, 400000, 500000, 543210, 700000, 1100000, 2000000, 2000020])
 def test_random_scenes_and_options_bit_identical_to_oracle(rt, first, capsys):
     import fuzz_parity
     argv = sys.argv

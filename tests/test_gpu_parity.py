@@ -542,8 +542,16 @@ def _check_against_fixture(t, n, fixture, scene, what, gate=(0.85, 1.15), zmax=6
     for name in what["blocks"]:
         z = _z(_blocks(t[name], block), n, g["blocks_" + name], nb)
         assert z.size > 500, (name, z.size)
-        zs.append(z)
         report["z2_" + name] = float(np.mean(z ** 2))
+        if name in what.get("sub_poisson", ()):
+            # A quasi-random launch (Sobol, stratified) puts the same number of photons into every column, so the
+            # GPU side of a tally that the direct beam feeds varies LESS than the Poisson law the z-score assumes
+            # (the fixture's side is Poisson): mean(z^2) below 1 is the launch doing its job. Gated from above
+            # only, down to the floor where the GPU side adds no variance at all, and kept out of the pooled figure.
+            floor = 0.9 * n / (n + nb)
+            assert np.max(np.abs(z)) < zmax and floor < np.mean(z ** 2) < gate[1], (name, np.mean(z ** 2), np.max(np.abs(z)))
+            continue
+        zs.append(z)
         assert np.max(np.abs(z)) < zmax and gate[0] < np.mean(z ** 2) < gate[1], (name, np.mean(z ** 2), np.max(np.abs(z)))
     zl = np.concatenate([_z(t["atmos_direct"].sum(axis=(1, 2)), n, g["level_direct"], nb),
                          _z(t["atmos_diffuse"].sum(axis=(1, 2)), n, g["level_diffuse"], nb)])

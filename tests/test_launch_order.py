@@ -21,9 +21,16 @@ def test_small_grids_keep_rows():
     assert rt.choose_launch_order(128, 128, 128, 1 << 20, ngpus=2) == (5, 0)
 
 
-def test_no_whole_pass_means_uniform_positions():
-    assert rt.choose_launch_order(16, 12, 10, 1 << 16) == (-1, 0)              # 192 columns never divide 2^16
-    assert rt.choose_launch_order(1024, 1024, 128, (1 << 28) + 1) == (-1, 0)
-    assert rt.choose_launch_order(1024, 1024, 128, 1 << 19) == (-1, 0)         # fewer photons than columns
+def test_no_whole_pass_means_the_sobol_launch():
+    """when no whole-pass k exists the automatic order is the Sobol sequence (even for any count
+    on any grid), not Poisson positions -- in particular for every power-of-two photon count on the reference's own
+    240 x 240-column io grid (raytracer_3d_io.cu:15-17), where 57600 * 2^k never divides 2^n."""
+    S = rt.tracer.LAUNCH_SOBOL
+    assert S == -2
+    assert rt.choose_launch_order(16, 12, 10, 1 << 16) == (S, 0)              # 192 columns never divide 2^16
+    assert rt.choose_launch_order(1024, 1024, 128, (1 << 28) + 1) == (S, 0)
+    assert rt.choose_launch_order(1024, 1024, 128, 1 << 19) == (S, 0)         # fewer photons than columns
+    for e in range(15, 41):
+        assert rt.choose_launch_order(240, 240, 284, 1 << e) == (S, 0), e
     for k, tile in (rt.choose_launch_order(16, 12, 10, 192 * 7 << 3),):
         assert (k, tile) == (3, 0)

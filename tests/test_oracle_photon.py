@@ -141,3 +141,65 @@ def test_slab_derivation():
     assert sl.kmaj[0] == np.float32(1e-4) and sl.kmaj[1] == np.float32(1e-4) + np.float32(5e-3)
     sl = O.oracle_slabs(scenes.rayleigh_column())
     assert sl.nslab == 1 and (sl.k_lo, sl.k_hi) == (-1, -1) and sl.zface[1] == 3200.0
+
+
+# ---- Sobol launch (reference: raytracer_kernels.cu:239-253, 331) ------------------
+def _elementary_counts_ok(words, m):
+    """every elementary interval 2^-a x 2^-(m-a) of the unit square holds exactly one of the 2^m points"""
+    x, y = words[:, 0].astype(np.uint64), words[:, 1].astype(np.uint64)
+    for a in range(m + 1):
+        box = ((x >> np.uint64(32 - a)) << np.uint64(m - a)) | (y >> np.uint64(32 - (m - a))) if 0 < a < m else \
+            (y >> np.uint64(32 - m) if a == 0 else x >> np.uint64(32 - m))
+        if not np.array_equal(np.sort(box), np.arange(1 << m, dtype=np.uint64)):
+            return False
+    return True
+
+
+def test_sobol_words_are_the_joe_kuo_sequence_of_scipy():
+    """The unshifted launch words against an independent published implementation: scipy.stats.qmc.Sobol holds the
+    Joe-Kuo direction numbers (dimensions 0 and 1 are the tables cuRAND hands the reference, raytracer_3d.cu:135-140)
+    and walks them in Gray-code order, so its point n is the oracle's point n ^ (n >> 1)."""
+    qmc = pytest.importorskip("scipy.stats.qmc")
+    n = 1 << 14
+    want = qmc.Sobol(d=2, scramble=False, bits=32).random(n)
+    ids = np.arange(n)
+    got = O.sobol_words(0, ids ^ (ids >> 1), shifted=False)
+    assert np.array_equal(got.astype(np.float64) / 2.0 ** 32, want)
+
+
+@pytest.mark.parametrize("m,first", [(4, 0), (7, 5 << 7), (10, 3 << 10), (12, (1 << 32) - (1 << 12)), (12, (7 << 32) + (9 << 12))])
+def test_sobol_launch_fills_every_elementary_interval(m, first):
+    """(0,2)-sequence property, digital shift included: an aligned block of 2^m consecutive photon IDs puts exactly
+    one point into each elementary interval 2^-a x 2^-(m-a), a = 0..m -- also in the last block below a multiple of
+    2^32 and in blocks beyond it (their shift is another draw)."""
+    w = O.sobol_words(99, np.arange(first, first + (1 << m)), shifted=True)
+    assert _elementary_counts_ok(w, m)
+    assert not _elementary_counts_ok(O.sobol_words(99, np.arange(first + 1, first + 1 + (1 << m))), m) or m < 3
+
+
+def test_sobol_launch_is_even_on_a_grid_that_is_no_power_of_two():
+    """toa_down of the oracle on 16 x 12 columns (192: no whole-pass k exists for a power-of-two count): with the
+    Sobol launch the per-column counts of 2^16 photons vary far less than Poisson (variance = mean = 341), for a
+    range that starts anywhere; with uniform positions they are Poisson."""
+    sc = scenes.tiny()
+    n = 1 << 16
+    for begin in (0, 12345):
+        t, _ = O.photon_oracle(sc, 5, begin, n, launch_log2k=-2)
+        td = t["toa_down"].astype(np.float64)
+        assert int(td.sum()) == n and O.balance(t) == 0
+        assert td.var() < 0.05 * td.mean(), (begin, td.var(), td.mean())
+    t, _ = O.photon_oracle(sc, 5, 0, n)
+    td = t["toa_down"].astype(np.float64)
+    assert 0.7 * td.mean() < td.var() < 1.4 * td.mean()
+
+
+def test_sobol_launch_changes_only_where_photons_enter():
+    """Same seed, same IDs: the Sobol launch moves the entry points, the global fractions stay within noise."""
+    sc = scenes.tiny()
+    n = 200_000
+    a, _ = O.photon_oracle(sc, 8, 0, n)
+    b, _ = O.photon_oracle(sc, 8, 0, n, launch_log2k=-2)
+    assert O.balance(b) == 0 and int(b["toa_down"].sum()) == n
+    for name in O.TALLY_NAMES[1:]:
+        pa, pb = int(a[name].sum()) / n, int(b[name].sum()) / n
+        assert abs(pa - pb) < 5 * np.sqrt(max(pa * (1 - pa), 1e-9) * 2 / n), name

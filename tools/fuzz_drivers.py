@@ -37,7 +37,7 @@ def main():
         e = int(rng.choice([16, 17]))
         n = 1 << e
         seed = int(rng.integers(0, 1 << 40))
-        launch = str(rng.choice(["auto", "auto", "uniform", "0", "2", "4"]))
+        launch = str(rng.choice(["auto", "auto", "uniform", "0", "2", "4", "sobol"]))
         split = bool(rng.random() < 0.3)
         runs = [e - 1, e - 1] if split else [e]
         ncol = scene.itot * scene.jtot
@@ -46,6 +46,8 @@ def main():
             k, tile = rt.choose_launch_order(scene.itot, scene.jtot, scene.ktot, 1 << runs[0])
         elif launch == "uniform":
             k, tile = -1, 0
+        elif launch == "sobol":
+            k, tile = -2, 0
         else:
             k, tile = int(launch), 0
         args = [f"--seed={seed}", f"--launch={launch}"]

@@ -6,7 +6,7 @@ kernels against oracle/photon_oracle.c, every tally and event counter bit for bi
 without changing what earlier case numbers mean: launch sort and tiled launch order (all), kernels without event
 counters and several sort batches (from 300 000), grids of whole 32-column tiles (400 000), split calls through
 rt_trace_noalloc (500 000), grids of one to four cells per axis (700 000), any sun angle and a context used twice
-with a new sun or new optics (1 100 000).
+with a new sun or new optics (1 100 000), the Sobol launch (2 000 000).
 
 Test infrastructure like tests/ (it calls the oracle as the checker). Usage, on the GPU box:
     python tools/fuzz_parity.py [cases=200] [first_case=0]
@@ -105,6 +105,12 @@ def main():
                               azimuth=float(rng3.uniform(0.0, 360.0)), albedo=float(rng3.choice([0.0, 0.35, 1.0])),
                               scale=float(rng3.choice([0.25, 3.0])), n=int(rng3.choice([1, 999, 30000])),
                               seed=int(rng3.integers(0, 1 << 62)), upload=bool(rng3.random() < 0.5))
+        if case >= 2000000:      # round 3: the Sobol launch (uniform-launch cases become Sobol with probability 1/2) and
+            rng4 = np.random.default_rng(33000 + case)      # ID ranges around multiples of 2^32, where its shift changes
+            if log2k < 0 and rng4.random() < 0.5:
+                log2k = -2
+                if rng4.random() < 0.4:
+                    pid0 = (int(rng4.integers(1, 100)) << 32) - int(rng4.integers(0, max(n, 2)))
         desc = dict(case=case, kind=kind, grid=(scene.itot, scene.jtot, scene.ktot), albedo=scene.albedo, zenith=scene.zenith_deg,
                     pool=pool, supergrid=sg, levels=levels, tau_milli=tau_milli, log2k=log2k, planar=planar,
                     fixed_dot=fixed_dot, chunk=chunk, th_launch=thl, n=n, pid0=pid0, stats=stats,
