@@ -62,7 +62,7 @@ def parse():
                     help="scenes timed on the CPU besides the benchmarked one (SURVEY.md section 8d asks for C1 and C3)")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--launch-log2k", type=int, default=None,
-                    help="stratified launch: 2^k consecutive photon IDs per column (-1 = uniform launch positions); "
+                    help="stratified launch: 2^k consecutive photon IDs per column (-1 = uniform launch positions, -2 = Sobol); "
                          "used only when every GPU's batch is a whole number of passes over the columns. Default: 8 on "
                          "grids beyond the caches (packed cells > 256 MiB), 5 on smaller ones, as the drivers' --launch=auto")
     ap.add_argument("--launch-tile-log2", type=int, default=None,
@@ -323,8 +323,8 @@ def main():
                        "launch": (f"stratified, 2^{launch_log2k} consecutive photon ids per column, columns "
                                   + (f"in tiles of {1 << launch_tile_log2} x {1 << launch_tile_log2}, " if launch_tile_log2 > 0 else "row by row, ") +
                                   f"{n_per_gpu // ((scene.itot * scene.jtot) << launch_log2k)} sweeps of the domain top per GPU per step"
-                                  if launch_log2k >= 0 else "uniform random positions (the reference's sampling); photon ids taken in the order "
-                                  "of their launch tile -- sorted on the device inside the timed region, kernel_ms includes the sort's passes")},
+                                  if launch_log2k >= 0 else ("Sobol sequence indexed by the photon id (the reference's launch)" if launch_log2k == -2 else "uniform random positions") +
+                                  "; photon ids taken in the order of their launch tile -- sorted on the device inside the timed region, kernel_ms includes the sort's passes")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "rt_trace_pool_kernel", "kernel_ms": avg_kernel_ms,
@@ -334,23 +334,34 @@ def main():
             "scheduler": tr.sched_stats(),
         }
         if world == 1 and launch_log2k >= 0 and not args.no_uniform_leg:
-            # beside the headline: the same step with the reference's own launch sampling (uniform positions, the
-            # library default), where the pool kernel sorts each batch's photon ids by launch tile on the device
-            tr.set_option("launch_log2k", -1)
-            tr.prepare()
-            base = (args.warmup + args.steps + 1) * n_per_gpu
-            tr.reset(); tr.trace(args.seed, base, n_per_gpu); tr.synchronize()
-            torch.cuda.synchronize()
-            tu = time.perf_counter()
-            for k in range(args.steps):
-                tr.reset(); tr.trace(args.seed, base + (k + 1) * n_per_gpu, n_per_gpu)
-            tr.synchronize()
-            torch.cuda.synchronize()
-            tu = time.perf_counter() - tu
-            tu_bal = rt.photon_balance(tr.tallies())
-            out["uniform_launch"] = {"value": n_per_gpu * args.steps / tu, "unit": "photons/s", "ms_per_step": tu / args.steps * 1e3,
-                                     "steps": args.steps, "balance": tu_bal,
-                                     "launch": "uniform random positions; photon ids sorted by launch tile on the device, inside the timed region"}
+            # beside the headline: the same step with the two launch samplings that are functions of the photon ID alone
+            # and work for any photon count on any grid -- the Sobol sequence (the reference's own launch,
+            # raytracer_kernels.cu:239-253, 331; what the drivers' --launch=auto takes when no whole pass exists) and
+            # uniform Philox positions (the library default) -- where the pool kernel sorts each batch's photon ids by
+            # launch tile on the device, inside the timed region
+            def launch_leg(mode, slot, what):
+                tr.set_option("launch_log2k", mode)
+                tr.prepare()
+                base = (args.warmup + args.steps + 1 + slot * (args.steps + 1)) * n_per_gpu
+                tr.reset(); tr.trace(args.seed, base, n_per_gpu); tr.synchronize()
+                torch.cuda.synchronize()
+                tu = time.perf_counter()
+                for k in range(args.steps):
+                    tr.reset(); tr.trace(args.seed, base + (k + 1) * n_per_gpu, n_per_gpu)
+                tr.synchronize()
+                torch.cuda.synchronize()
+                tu = time.perf_counter() - tu
+                tal = tr.tallies()
+                td = tal["toa_down"].astype(np.float64)
+                return {"value": n_per_gpu * args.steps / tu, "unit": "photons/s", "ms_per_step": tu / args.steps * 1e3,
+                        "steps": args.steps, "balance": rt.photon_balance(tal),
+                        "vs_headline": (n_per_gpu * args.steps / tu) / value,
+                        "toa_down_variance_over_mean": float(td.var() / td.mean()),
+                        "launch": what}
+            out["sobol_launch"] = launch_leg(-2, 0, "Sobol sequence indexed by the photon id, digitally shifted per seed (the reference's "
+                                             "launch, raytracer_kernels.cu:239-253); whole nets of ids taken box by box of the domain top "
+                                             "through the net's inverse (no sort, no list), the rest sorted by launch tile")
+            out["uniform_launch"] = launch_leg(-1, 1, "uniform random positions; photon ids sorted by launch tile on the device, inside the timed region")
             tr.set_option("launch_log2k", launch_log2k)
             tr.prepare()
             uprof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_uniform.json")

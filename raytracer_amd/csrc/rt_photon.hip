@@ -195,6 +195,11 @@ struct ColdBlock
     const uint32_t* sorted;       // launch sort: the launch's IDs (relative to pid_begin) in the order they are taken; or null
     uint32_t toa_done;            // launch sort: toa_down of this launch is already counted (rt_sort_toa_kernel)
     uint32_t sob_x, sob_y;        // Sobol launch: digital shift of this launch's 2^32-ID block
+    // Sobol launch in box order (sobol_position_to_id below; sob_a = 0: off): the launch's IDs are taken box by box of
+    // a 2^sob_a x 2^sob_b partition of the domain top instead of in ascending order or through a sorted list
+    uint32_t sob_a, sob_b, sob_tile_log2, sob_klog2;
+    uint32_t sob_b0;              // (low word of the launch's first ID) >> (sob_a + sob_b): its first net of the block
+    uint32_t sob_tinv[16];        // unknown ID bits a .. a+b-1 = XOR of sob_tinv[r] over the set bits r of the residual
 };
 
 // The cold block through the constant address space: its contents do not change while the tracer runs (the kernel
@@ -296,6 +301,37 @@ __device__ __forceinline__ uint32_t launch_column_index_exact(int log2k, uint32_
 __device__ __forceinline__ uint32_t launch_column_index_exact(const TraceArgs& a, uint64_t pid, uint32_t key0, uint32_t key1)
 {
     return launch_column_index_exact(a.launch_log2k, a.ncol, pid, key0, key1);
+}
+
+// Sobol launch in box order: which photon ID a launch takes at position p (< 2^31) of its ID range. Any 2^m
+// consecutive IDs that start at a multiple of 2^m (m = a + b) are a (0,m,2)-net: exactly one of them falls into each
+// box of the 2^a x 2^b partition of the domain top. So the ID in box (i, j) of net B is the solution of a linear
+// system over GF(2) -- the low a bits of the ID are the reversed bits of i (dimension 0 is the radical inverse), and
+// the next b bits follow from j through the inverse of a b x b block of the Pascal matrix, which the host hands over
+// as sob_tinv (build_sobol_order). The launch walks the boxes tile by tile (tiles of 2^T x 2^T boxes, as the tiled
+// stratified order counts its columns) and takes 2^k nets per box at a time (positions p = ((sweep * boxes + box)
+// << k) + r, net = (sweep << k) + r): the photons in flight together share a neighbourhood, and runs of 2^k
+// consecutive lanes enter one column -- the locality of the stratified order without its restriction to whole
+// passes over a power-of-two number of columns, and without the launch sort's passes. Scheduling only: every ID of
+// the range is taken exactly once whatever the grid's shape (the boxes need not be the columns).
+__device__ __forceinline__ uint32_t sobol_position_to_id(ColdPtr cb, uint32_t p)
+{
+    const uint32_t a = cb->sob_a, b = cb->sob_b, T = cb->sob_tile_log2, k = cb->sob_klog2, m = a + b;
+    const uint32_t q = p >> k, sweep = q >> m, c = q & ((1u << m) - 1u);
+    const uint32_t net = cb->sob_b0 + (sweep << k) + (p & ((1u << k) - 1u));
+    const uint32_t t = c >> (2u * T), w = c & ((1u << (2u * T)) - 1u);
+    const uint32_t tj = t >> (a - T), ti = t & ((1u << (a - T)) - 1u);
+    const uint32_t i = (ti << T) | (w & ((1u << T) - 1u)), j = (tj << T) | (w >> T);
+    const uint32_t low = __builtin_bitreverse32(i ^ (cb->sob_x >> (32u - a))) >> (32u - a);
+    const uint32_t known = (net << m) | low;
+    uint32_t x0, x1;
+    rt::sobol_2d(known, 0u, cb->sob_y, x0, x1);
+    const uint32_t rhs = j ^ (x1 >> (32u - b));
+    uint32_t u = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        u ^= (uint32_t)(-(int32_t)((rhs >> r) & 1u)) & cb->sob_tinv[r];
+    return known | (u << a);
 }
 
 enum : int { ST_LAUNCH = 0, ST_TRAVERSE = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_SCATTER = 4, ST_DONE = 5, ST_REFLECT = 6 };
@@ -1292,6 +1328,8 @@ rt_trace_pool_kernel(const PoolArgs a)
                 uint64_t my_pid = wave_next + (uint64_t)lane;
                 if (const uint32_t* const order = cb->sorted)       // launch sort: position in the launch -> ID
                     my_pid = cb->pid_begin + (uint64_t)order[(uint32_t)(my_pid - cb->pid_begin)];
+                else if (cb->sob_a != 0u)                           // Sobol launch in box order
+                    my_pid = (cb->pid_begin & ~0xffffffffull) | (uint64_t)sobol_position_to_id(cb, (uint32_t)(my_pid - cb->pid_begin));
                 const uint32_t pid_lo = (uint32_t)my_pid, pid_hi = (uint32_t)(my_pid >> 32);
                 uint32_t lk0 = key0, lk1 = key1;            // see the event stage: no hoisted, spilled round keys
                 asm volatile("" : "+s"(lk0), "+s"(lk1));
@@ -1907,6 +1945,7 @@ struct rt_context
     int chunk = 256;                    // pool kernel: photon IDs a wave takes from the cursor at a time
     int launch_log2k = -1;            // >= 0: stratified launch, 2^k consecutive photon IDs per column
     int launch_tile_log2 = 0;         // stratified launch: columns counted in tiles of 2^this columns square (0 = row-major)
+    bool sobol_boxes = true;          // Sobol launch, pool kernel: whole nets of IDs are taken box by box (no sort)
     int launch_sort = -1;             // uniform launch, pool kernel: take the IDs in the order of their launch tile
                                       // (1; 0 = never; -1 = automatic: calls of 2^19 photons or more)
     int sort_batch_log2 = 30;         // IDs sorted (and traced) at a time: 4 bytes of list each (every batch ends with a
@@ -2348,6 +2387,62 @@ void sobol_shift(uint64_t seed, uint64_t block, uint32_t& sx, uint32_t& sy)
     sx = w[0]; sy = w[1];
 }
 
+// Sobol launch in box order (sobol_position_to_id): the partition of the domain top into 2^a x 2^b boxes -- about one
+// box per column, at most 2^15 per axis -- whose nets of 2^(a+b) IDs the launch walks.
+void sobol_boxes(const rt_context* c, uint32_t& a, uint32_t& b)
+{
+    const auto ceil_log2 = [](int n) { uint32_t l = 0; while ((1 << l) < n && l < 15u) ++l; return l < 1u ? 1u : l; };
+    a = ceil_log2(c->itot); b = ceil_log2(c->jtot);
+}
+uint32_t sobol_net_log2(const rt_context* c) { uint32_t a, b; sobol_boxes(c, a, b); return a + b; }
+
+// The cold block's share of a launch in box order over IDs [b0, b0 + nb): whole nets inside one block of 2^32 IDs,
+// nb <= 2^30. The b x b block T of the Pascal matrix that ties ID bits a .. a+b-1 to the top b bits of dimension 1
+// (T[q][k] = 1 iff the binary digits of a + k contain those of q) is inverted over GF(2) here; sob_tinv[r] is the
+// column of the inverse that belongs to bit r of the residual (bit b-1-q of the box index <-> output bit 31-q).
+void build_sobol_order(const rt_context* c, uint64_t b0, uint64_t nb, ColdBlock& cb)
+{
+    uint32_t a, b;
+    sobol_boxes(c, a, b);
+    const uint32_t m = a + b;
+    uint32_t rows[16], inv[16];
+    for (uint32_t q = 0; q < b; ++q)
+    {
+        rows[q] = 0u; inv[q] = 1u << q;
+        for (uint32_t k = 0; k < b; ++k)
+            if (((a + k) & q) == q) rows[q] |= 1u << k;
+    }
+    for (uint32_t col = 0; col < b; ++col)          // Gauss-Jordan; T is regular because the sequence is a (0,2)-sequence
+    {
+        uint32_t piv = col;
+        while (piv < b && !((rows[piv] >> col) & 1u)) ++piv;
+        if (piv == b) { cb.sob_a = 0u; return; }    // (cannot happen; the launch then takes the ordinary path's order)
+        std::swap(rows[col], rows[piv]); std::swap(inv[col], inv[piv]);
+        for (uint32_t r = 0; r < b; ++r)
+            if (r != col && ((rows[r] >> col) & 1u)) { rows[r] ^= rows[col]; inv[r] ^= inv[col]; }
+    }
+    // inv[k] bit q = (T^-1)[k][q]: unknown bit k = XOR over q of inv[k][q] * residual[q]
+    for (uint32_t r = 0; r < 16; ++r)
+    {
+        cb.sob_tinv[r] = 0u;
+        if (r < b)
+            for (uint32_t k = 0; k < b; ++k)
+                cb.sob_tinv[r] |= ((inv[k] >> (b - 1u - r)) & 1u) << k;
+    }
+    // tiles of boxes and nets per visit as the stratified order chooses them (choose_launch_order): beyond the caches
+    // tiles of 32 x 32 and up to 2^8 nets at a time, else rows and up to 2^5 (more photons into one column at a time
+    // contend for the same tally words on small grids)
+    const bool beyond = !small_grid(c);
+    const uint32_t npass = (uint32_t)(nb >> m);
+    uint32_t tile = beyond ? 5u : 0u, kmax = beyond ? 8u : 5u, k = 0u;
+    if (c->launch_tile_log2 > 0) tile = (uint32_t)c->launch_tile_log2;
+    if (tile > a) tile = a;
+    if (tile > b) tile = b;
+    while (k < kmax && ((npass >> (k + 1u)) << (k + 1u)) == npass) ++k;
+    cb.sob_a = a; cb.sob_b = b; cb.sob_tile_log2 = tile; cb.sob_klog2 = k;
+    cb.sob_b0 = (uint32_t)b0 >> m;
+}
+
 // Launches the tracer for photon IDs [pid_begin, pid_begin + count). `cursor` / `cold`: the device words the pool
 // kernel takes its photon-ID cursors and cold block from -- the context's own allocation (rt_trace) or the static
 // scratch (rt_trace_noalloc, which must not allocate: it refuses instead of building majorants).
@@ -2410,19 +2505,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     bool sorted = c->pool > 0 && c->launch_log2k < 0 &&
                   (c->launch_sort == 1 || (c->launch_sort < 0 && count >= (1ull << 19)));
     const uint64_t batch = sorted ? (1ull << c->sort_batch_log2) : count;
-    if (sorted && (size_t)(count < batch ? count : batch) > c->sort_capacity)
-    {
-        if (noalloc)
-            sorted = false;
-        else
-        {
-            const size_t need = (size_t)(count < batch ? count : batch);
-            if (c->d_sort) RT_HIP(hipFree(c->d_sort));
-            c->d_sort = nullptr; c->sort_capacity = 0;
-            RT_HIP(hipMalloc(&c->d_sort, sizeof(uint32_t) * (need + kSortMaxTiles * (1 + sort_blocks(c)))));
-            c->sort_capacity = need;
-        }
-    }
+    // (the list is allocated by the first batch that is sorted: a Sobol launch whose IDs go in box order never needs it)
 
     if (!noalloc) RT_HIP(hipEventRecord(c->ev_start, c->stream));
     if (c->pool > 0)
@@ -2477,7 +2560,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         memset(&so, 0, sizeof(so));
         if (sorted)
         {
-            so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;
+            so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;   // (or once allocated, below)
             so.seed = seed;
             so.tile_shift = (uint32_t)c->sort_tile_log2;
             const auto tiles_along = [&](int n) { return (uint32_t)((n + (1 << so.tile_shift) - 1) >> so.tile_shift); };
@@ -2495,12 +2578,42 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         {
             const uint64_t b0 = pid_begin + done;
             nb = count - done < batch ? count - done : batch;
+            bool in_boxes = false;          // Sobol launch in box order: needs neither a sort nor a list
+            cb.sob_a = 0u;
             if (sobol)
             {
                 const uint64_t to_block_end = (((b0 >> 32) + 1ull) << 32) - b0;
-                if (nb > to_block_end) nb = to_block_end;
+                uint64_t span = count - done < to_block_end ? count - done : to_block_end;
                 sobol_shift(seed, b0 >> 32, cb.sob_x, cb.sob_y);
                 so.sobol = 1; so.sob_x = cb.sob_x; so.sob_y = cb.sob_y;
+                if (c->sobol_boxes)
+                {
+                    // the stretch of whole nets (2^m consecutive IDs from a multiple of 2^m) goes in box order; what lies
+                    // ahead of the first net, and what is left behind the last, takes the ordinary path
+                    const uint64_t net = 1ull << sobol_net_log2(c), head = (net - (b0 & (net - 1ull))) & (net - 1ull);
+                    const uint64_t whole = (span < (1ull << 30) ? span : (1ull << 30)) & ~(net - 1ull);
+                    if (head != 0ull) span = head < span ? head : span;
+                    else if (whole != 0ull) { in_boxes = true; nb = whole; build_sobol_order(c, b0, nb, cb); }
+                }
+                if (!in_boxes) nb = span < batch ? span : batch;
+            }
+            // (what a Sobol launch leaves outside its whole nets is short: sorted only when that is worth five kernels)
+            bool sorted_now = sorted && !in_boxes &&
+                              !(sobol && c->sobol_boxes && c->launch_sort < 0 && nb < (1ull << 19));
+            if (sorted_now && (size_t)nb > c->sort_capacity)
+            {
+                if (noalloc)
+                    sorted_now = false;
+                else
+                {
+                    // room for the largest batch this call can still bring
+                    const size_t need = (size_t)(count - done < batch ? count - done : batch);
+                    if (c->d_sort) RT_HIP(hipFree(c->d_sort));
+                    c->d_sort = nullptr; c->sort_capacity = 0;
+                    RT_HIP(hipMalloc(&c->d_sort, sizeof(uint32_t) * (need + kSortMaxTiles * (1 + sort_blocks(c)))));
+                    c->sort_capacity = need;
+                    so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;
+                }
             }
             // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
             // every resident wave still finds work
@@ -2509,9 +2622,9 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
             cb.pid_begin = b0; cb.total = nb;
             cb.sub_size = (((nb + kXcds - 1) / kXcds + chunk - 1) / chunk) * chunk;
             cb.chunk = chunk;
-            cb.sorted = sorted ? c->d_sort : nullptr;
-            cb.toa_done = toa_pass ? 1u : 0u;
-            if (sorted)
+            cb.sorted = sorted_now ? c->d_sort : nullptr;
+            cb.toa_done = (toa_pass && sorted_now) ? 1u : 0u;
+            if (sorted_now)
             {
                 so.pid_begin = b0; so.n = (uint32_t)nb;
                 const uint64_t max_blocks = sort_blocks(c);
@@ -2818,6 +2931,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
         c->launch_sort = (int)value;
         if (wants_fine(c) != c->built_fine) c->maj_dirty = true;
     }
+    else if (!strcmp(name, "sobol_boxes")) c->sobol_boxes = value != 0;
     else if (!strcmp(name, "sort_tile_log2"))
     {
         if (value < 0 || value > 12) return fail(RT_ERR_ARG, "rt_set_option: sort_tile_log2 %lld outside [0,12]", value);

@@ -59,6 +59,23 @@ def test_sobol_launch_sorted_by_tile_is_still_the_oracle(rt, n, batch_log2, tile
     tr.close()
 
 
+@pytest.mark.parametrize("grid,begin,n", [((300, 70), (9 << 32) - 200_000, 500_000), ((64, 64), 4096 * 5, 4096 * 37),
+                                          ((33, 5), 7, 100_000), ((1, 1), 0, 5000), ((256, 2), 1 << 20, (1 << 18) + 3)])
+def test_sobol_launch_in_box_order_takes_every_id_once(rt, grid, begin, n):
+    """Whole nets of a Sobol launch (2^m consecutive IDs from a multiple of 2^m, 2^m boxes ~ columns) are taken box by
+    box through the inverse of the net (option sobol_boxes, default on) instead of through a sorted list: scheduling
+    only, so the tallies and event counts are the oracle's -- ragged grids whose boxes are not their columns, ranges with
+    a head and a tail outside the whole nets and across a multiple of 2^32 -- and equal those of the sorted path."""
+    scene = rt.scenes.cumulus(grid[0], grid[1], 8, 100.0, 80.0, 60.0, n_clouds=4, seed=3, z_base=120.0, z_top=360.0)
+    want, ev = O.photon_oracle(scene, 21, begin, n, launch_log2k=SOBOL)
+    for boxes in (1, 0):
+        tr = rt.PhotonTracer.from_scene(scene, stats=1, launch_log2k=SOBOL, sobol_boxes=boxes)
+        tr.trace(21, begin, n); tr.synchronize()
+        _assert_same(tr.tallies(), want)
+        assert tr.events() == ev
+        tr.close()
+
+
 def test_device_sobol_words_equal_the_oracle_and_fill_every_elementary_interval(rt):
     """rt_selftest_launch: the device's words for IDs either side of 2^32 equal the oracle's; and every aligned block
     of 2^m consecutive IDs puts exactly one point into each elementary interval 2^-a x 2^-(m-a), a = 0..m, for
