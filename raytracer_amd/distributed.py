@@ -110,6 +110,8 @@ class ShardedTracer:
         self.pending = [None] * nbuf
         self.exchanged = [False] * nbuf
         self.steps = 0
+        self.step_stream = [None] * nbuf      # the stream each buffer's step was enqueued on (checked by result())
+        self.timeout_s = float(__import__("os").environ.get("RT_COLLECTIVE_TIMEOUT_S", "600"))
         _follow_torch_stream(tracer, self.tallies[0])
         if self.overlap and reserve_lds and hasattr(tracer, "set_option"):
             tracer.set_option("pool_waves_per_cu", POOL_WAVES_BESIDE_A_COLLECTIVE)
@@ -124,7 +126,12 @@ class ShardedTracer:
         import torch.distributed as dist
         b = self.steps % len(self.tallies)
         self.steps += 1
+        # The collective is ordered against torch's CURRENT stream at the moment of the call, so the tracer follows it
+        # on every step (not once at construction): a caller inside `with torch.cuda.stream(s)` gets trace, narrowing,
+        # all-reduce, widening and reset all on s. A buffer stays with the stream of its step until its result is in.
+        _follow_torch_stream(self.tracer, self.tallies[b])
         self._finish(b)
+        self.step_stream[b] = self._current_stream_id()
         tally = self.tallies[b]
         if len(self.tallies) > 1:
             self.tracer.bind_tally_tensor(tally)
@@ -160,11 +167,43 @@ class ShardedTracer:
             self.tracer.widen_tallies(self.wire[b], self.tallies[b])
         self.exchanged[b] = True
 
+    def _current_stream_id(self):
+        if self.device.type != "cuda":
+            return None
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
     def _finish(self, b):
         if self.pending[b] is not None:
-            self.pending[b].wait()          # torch's current stream waits for the collective; the host does not
+            # work.wait() makes torch's current stream wait for the collective (the host does not block), and the
+            # widening kernel is enqueued behind it on the tracer's stream: both must be the stream the step ran on,
+            # or the widening could run ahead of the all-reduce it depends on
+            now = self._current_stream_id()
+            if self.step_stream[b] is not None and now != self.step_stream[b]:
+                raise RuntimeError(f"ShardedTracer: step of buffer {b} was enqueued on stream {self.step_stream[b]:#x}, its "
+                                   f"result is asked for under stream {now:#x}; call step() and result() under one stream")
+            _follow_torch_stream(self.tracer, self.tallies[b])
+            self.pending[b].wait()
             self.pending[b] = None
             self._after_exchange(b)
+
+    def _host_wait(self, what):
+        """Blocks the host until everything enqueued so far on the current stream is done -- with a bound: a
+        cross-stream wait that never completes becomes an error that says what was pending, not a silent hang
+        (RT_COLLECTIVE_TIMEOUT_S, default 600)."""
+        if self.device.type != "cuda":
+            return
+        import time
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        t0, pause = time.monotonic(), 1e-5
+        while not ev.query():
+            if time.monotonic() - t0 > self.timeout_s:
+                state = [f"buffer {b}: all-reduce {'pending' if w is not None and not w.is_completed() else 'done'}"
+                         for b, w in enumerate(self.pending)]
+                raise RuntimeError(f"ShardedTracer: {what} not complete after {self.timeout_s:.0f} s on stream "
+                                   f"{self._current_stream_id():#x} ({'; '.join(state)})")
+            time.sleep(pause)
+            pause = min(pause * 2, 1e-3)
 
     def drain(self):
         """Every started all-reduce is complete (in stream order) when this returns."""
@@ -176,6 +215,7 @@ class ShardedTracer:
         import torch.distributed as dist
         self._finish(handle)
         tally = self.tallies[handle]
+        self._host_wait(f"result of buffer {handle} (trace, all-reduce, widening)")
         if self.wire32 and self.exchanged[handle] and int(self.wire[handle][-1].item()) != 0:
             # a count too large for 32 bits somewhere: every rank sees the same flag sum and repeats in 64 bits
             dist.all_reduce(tally, op=dist.ReduceOp.SUM, group=self.group)

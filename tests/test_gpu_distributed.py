@@ -96,6 +96,49 @@ def test_rccl_world_size_one_overlapped_32bit_exchange(tmp_path):
         assert np.array_equal(got[k], want[k]), k
 
 
+def test_rccl_exchange_under_a_side_stream_and_stream_mismatch_is_refused(tmp_path):
+    """the collective is ordered against torch's CURRENT stream, so ShardedTracer follows it on every step
+    (not once at construction). The same overlapped 32-bit exchange under `with torch.cuda.stream(side)`, created
+    AFTER the ShardedTracer: bit-identical to single calls; a result asked for under another stream than its step's is
+    refused (the widening kernel would not be ordered behind the all-reduce); and the bounded host wait reports
+    instead of hanging when its limit is 0."""
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        scene = rt.scenes.tiny()
+        tr = rt.PhotonTracer.from_scene(scene, device=0)
+        st = rt.distributed.ShardedTracer(tr, "cuda:0", force_collective=True, overlap=True)
+        side = torch.cuda.Stream()
+        got, handles = [], []
+        with torch.cuda.stream(side):
+            for k, (seed, total, first) in enumerate(JOBS):
+                handles.append(st.step(seed, total, first))
+                assert st.step_stream[handles[-1]] == side.cuda_stream != 0
+                if k >= 1:
+                    got.append(st.result(handles[k - 1]).cpu().numpy().copy())
+        with pytest.raises(RuntimeError, match="under one stream"):
+            st.result(handles[-1])                      # default stream: not the step's
+        with torch.cuda.stream(side):
+            st.timeout_s = 0.0
+            st.step(1, 1 << 24, 0)                      # something still running: the bounded wait must say so, not hang
+            with pytest.raises(RuntimeError, match="not complete after 0 s"):
+                st.result(handles[-1])
+            st.timeout_s = 600.0
+            got.append(st.result(handles[-1]).cpu().numpy().copy())
+            st.drain()
+        side.synchronize()
+        tr.synchronize()
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+    want = _single_call(rt, rt.scenes.tiny())
+    for k in range(len(JOBS)):
+        assert np.array_equal(got[k], want[k]), k
+
+
 def test_narrow_and_widen_kernels(tmp_path):
     """rt_tallies_narrow / rt_tallies_widen either side of a 32-bit sum over two 'ranks' (two contexts on this GPU,
     the sum done with torch): equal to the 64-bit sum; a count at or above 2^31 raises the flag and the widening
