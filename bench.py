@@ -37,7 +37,11 @@ WORKLOADS = {
     "c2": ("rayleigh_column", 24, "C2 clear-sky Rayleigh column 64x64x64"),
     "c3": ("cumulus_c3", 28, "C3 broken cumulus 256x256x128, HG cloud + Lambertian surface (2^28 photons on one GPU)"),
     "c4": ("cumulus_c4", 28, "C4 LES cumulus 1024x1024x128 (2^31 photons per step over 8 GPUs)"),
+    # BASELINE config 5: the raytracer_3d_io flow as a zenith sweep with the full 3D absorption output per run
+    # (handled by sweep_bench below: a step is one run of the sweep, output files included)
+    "c5": ("io_default_grid", 26, "C5 zenith sweep of the raytracer_3d_io flow, 240x240x284 cells (raytracer_3d_io.cu:11-17)"),
 }
+C5_ZENITHS = (0.0, 15.0, 30.0, 45.0, 60.0, 75.0)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # The ceilings this kernel actually meets, measured on MI355X with tools/gather_rate.hip and
 # tools/valu_rate.hip (outputs: profiles/r1_microbench_*.txt): sectors of a multi-GiB array gathered at
@@ -77,6 +81,7 @@ def parse():
                     help="N > 1: wait for each step's all-reduce before the next step starts")
     ap.add_argument("--wire64", action="store_true",
                     help="N > 1: all-reduce the 64-bit tallies as they are (default: 32-bit counts on the wire)")
+    ap.add_argument("--outdir", default=None, help="--workload c5: where the runs' output files go (default: the system's temporary directory)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the collective code path even at world size 1")
     return ap.parse_args()
@@ -172,6 +177,131 @@ def cpu_baseline(scene, seconds, workload, extra_scenes):
     return out
 
 
+def sweep_bench(args, rt, torch):
+    """--workload c5 (one GPU): runs of 2^26 photons under six solar zenith angles with the grids resident, each run
+    followed by what raytracer_3d_io.cu:174-212 does after its kernel -- seven device-to-host copies and seven files.
+    Pipelined as the driver raytracer_3d_io_gpu does it: the copy of run k leaves one tally buffer over the library's
+    copy stream into pinned memory while run k+1 is traced into the other, and a host thread writes the files. A
+    step is one run; the timed region ends when the last file is closed. Measured beside it: the same runs strictly one
+    after another (the reference's order), the trace alone, and the same sweep on the C3 grid."""
+    import tempfile
+    import threading
+    n = 1 << (args.photons_log2 if args.photons_log2 is not None else WORKLOADS["c5"][1])
+
+    def one_grid(scene, outdir, steps, warmup):
+        tr = rt.PhotonTracer.from_scene(scene, device=0)
+        k, tile = rt.choose_launch_order(scene.itot, scene.jtot, scene.ktot, n)
+        tr.set_option("launch_log2k", k); tr.set_option("launch_tile_log2", tile)
+        tr.prepare()
+        sets = [tr.pinned_tallies() for _ in range(2)]
+        dirs = [os.path.join(outdir, f"run_{i:02d}") for i in range(2)]
+        for d in dirs:
+            os.makedirs(d, exist_ok=True)
+        state = {"bytes": 0, "write_s": 0.0, "err": None}
+
+        def write(ticket, arrays, d):
+            try:
+                if ticket is not None:
+                    tr.tallies_wait(ticket)
+                t0 = time.perf_counter()
+                rt.save_tallies(arrays, d)
+                state["write_s"] += time.perf_counter() - t0
+                state["bytes"] += sum(a.nbytes for a in arrays.values())
+            except Exception as exc:      # noqa: BLE001
+                state["err"] = exc
+
+        def sweep(jobs, first_job, pipelined):
+            writer = None
+            for j in range(jobs):
+                job = first_job + j
+                zen = C5_ZENITHS[job % len(C5_ZENITHS)]
+                tr.set_scene(zen, scene.azimuth_deg, scene.albedo)
+                tr.reset()
+                tr.trace(args.seed, job * n, n)
+                arrays = sets[j % 2][0]
+                if pipelined:
+                    ticket = tr.tallies_async(arrays)
+                    tr.swap_tally_buffer()
+                    if writer is not None:
+                        writer.join()
+                    writer = threading.Thread(target=write, args=(ticket, arrays, dirs[j % 2]))
+                    writer.start()
+                else:
+                    tr.synchronize()
+                    got = tr.tallies()          # seven blocking copies into pageable memory, as copy_from_gpu does
+                    write(None, got, dirs[j % 2])
+            if writer is not None:
+                writer.join()
+            tr.synchronize()
+            if state["err"] is not None:
+                raise state["err"]
+
+        sweep(warmup, 0, True)
+        state.update(bytes=0, write_s=0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sweep(steps, warmup, True)
+        piped = time.perf_counter() - t0
+        wrote, write_s = state["bytes"], state["write_s"]
+        t0 = time.perf_counter()
+        sweep(steps, warmup + steps, False)
+        serial = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        kernel_ms = []
+        for j in range(steps):
+            tr.set_scene(C5_ZENITHS[j % len(C5_ZENITHS)], scene.azimuth_deg, scene.albedo)
+            tr.reset(); tr.trace(args.seed, (warmup + 2 * steps + j) * n, n); tr.synchronize()
+            kernel_ms.append(tr.last_trace_ms())
+        trace_only = time.perf_counter() - t0
+        # the last run's files against the device's counts: what was written is what was traced
+        t = {name: np.fromfile(os.path.join(dirs[(steps - 1) % 2], name + ".bin"), dtype=np.uint64) for name in rt.TALLY_NAMES}
+        shaped = {name: v.reshape((scene.ktot, scene.jtot, scene.itot) if name.startswith("atmos") else (scene.jtot, scene.itot))
+                  for name, v in t.items()}
+        if rt.photon_balance(shaped) != 0 or int(t["toa_down"].sum()) != n:
+            raise SystemExit("bench c5: the files of the last run do not balance")
+        for s_ in sets:
+            tr.free_pinned(s_[1])
+        tr.set_option("stats", 1); tr.reset(); tr.trace(args.seed, 0, n); tr.synchronize(); ev = tr.events(); tr.set_option("stats", 0)
+        tr.close()
+        return {"grid": [scene.itot, scene.jtot, scene.ktot], "jobs": steps, "photons_per_job": n,
+                "launch_log2k": k, "output_bytes_per_job": wrote // max(steps, 1),
+                "end_to_end_photons_per_s": steps * n / piped, "jobs_per_s": steps / piped, "ms_per_job": piped / steps * 1e3,
+                "not_pipelined_photons_per_s": steps * n / serial, "not_pipelined_ms_per_job": serial / steps * 1e3,
+                "trace_only_photons_per_s": steps * n / trace_only, "trace_only_ms_per_job": trace_only / steps * 1e3,
+                "kernel_ms": sum(kernel_ms) / len(kernel_ms), "file_write_s_per_job": write_s / steps,
+                "file_write_GB_per_s": wrote / max(write_s, 1e-9) / 1e9, "events": ev}
+
+    steps = args.steps if args.steps != 3 else len(C5_ZENITHS)          # default: one sweep of the six angles
+    warmup = max(args.warmup, 1)
+    with tempfile.TemporaryDirectory(dir=args.outdir) as d:
+        io_scene = rt.scenes.cumulus(240, 240, 284, 100.0, 100.0, 30.0, n_clouds=60, seed=7, z_base=900.0, z_top=3000.0,
+                                     name="io_default_grid")
+        io = one_grid(io_scene, os.path.join(d, "io"), steps, warmup)
+        c3 = one_grid(rt.scenes.cumulus_c3(), os.path.join(d, "c3"), steps, warmup)
+        where = os.path.abspath(d)
+    alg = rt.algorithmic_bytes(io["events"], io["photons_per_job"])
+    achieved = alg / (io["kernel_ms"] * 1e-3) / 1e9
+    out = {"metric": "photons/sec (whole node)", "value": io["end_to_end_photons_per_s"], "unit": "photons/s", "n_gpus": 1,
+           "steps": steps, "warmup": warmup, "ms_per_step": io["ms_per_job"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": WORKLOADS["c5"][2] + f"; a step = one run of 2^{int(math.log2(n))} photons under the next of the zenith "
+                      f"angles {list(C5_ZENITHS)} (azimuth 20 deg) INCLUDING the download of the seven tally arrays and the "
+                      "seven output files (full 3D absorption fields) of raytracer_3d_io.cu:174-212, pipelined: copy and "
+                      "file writes of run k beside the trace of run k+1; value = end to end, measured",
+                      "photons_per_gpu_per_step": n, "parallelism": "one GPU (the sweep's runs are independent jobs)",
+                      "files_written_under": where},
+           "io_default_grid": {k: v for k, v in io.items() if k != "events"},
+           "c3_grid": {k: v for k, v in c3.items() if k != "events"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "rt_trace_pool_kernel", "kernel_ms": io["kernel_ms"],
+                        "algorithmic_bytes_per_photon": alg / io["photons_per_job"],
+                        "note": "the trace kernel of one run; end to end this workload is bound by the output files "
+                                f"({io['output_bytes_per_job'] / 1e6:.0f} MB per run at {io['file_write_GB_per_s']:.2f} GB/s)"}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(io_scene, args.cpu_seconds, "c5", [])
+    return out
+
+
 def main():
     args = parse()
     # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a five-line version banner at
@@ -200,6 +330,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    if args.workload == "c5":
+        if world != 1:
+            raise SystemExit("--workload c5 is a one-GPU measurement (its runs are independent jobs)")
+        torch.cuda.set_device(0)
+        out = sweep_bench(args, rt, torch)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.close(json_fd)
+        return
     if args.single_device:
         if args.backend != "gloo":
             raise SystemExit("--single-device needs --backend gloo (RCCL refuses two ranks on one GPU)")

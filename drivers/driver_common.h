@@ -22,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 namespace drv
@@ -55,6 +56,10 @@ struct Config
     // reference prepares for by copying its tally arrays to the device, raytracer_3d.cu:89, 98-104)
     bool resume = false;
     bool input_f64 = false;                   // sidecar says the data files hold float64
+    // --pipeline=1 (default) | 0: a sweep traces job k+1 while job k's seven arrays come down over a copy stream into
+    // pinned memory and a host thread writes its files (rt_download_tallies_async, rt_swap_tally_buffer); 0 = the
+    // reference's order, one thing after another (raytracer_3d_io.cu:156-212). The files are the same bytes either way.
+    bool pipeline = true;
 };
 
 inline void die(const std::string& msg)
@@ -165,6 +170,7 @@ inline void parse_args(int argc, char** argv, Config& c)
                 if (c.azimuth_deg.empty()) die("--azimuth needs at least one angle");
             }
             else if (key == "resume") c.resume = (val != "0");
+            else if (key == "pipeline") c.pipeline = (val != "0");
             else if (key == "seed") c.seed = std::stoull(val);
             else if (key == "ngpus") c.ngpus = std::stoi(val);
             else if (key == "indir") c.indir = val;
@@ -401,16 +407,61 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
               << std::chrono::duration<double>(t1 - t0).count() << " (s)" << std::endl;
     std::cout << slabs.cloud_min << " - " << slabs.cloud_max << std::endl;      // raytracer_3d.cu:130
 
-    std::vector<std::vector<uint64_t>> host(RT_N_TALLIES);
-    uint64_t* ptrs[RT_N_TALLIES];
-    for (int t = 0; t < RT_N_TALLIES; ++t)
+    // Host side of the results: two sets of the seven arrays in pinned memory (the copy engine writes them while the
+    // GPU traces the next job) -- one set when the pipeline is off.
+    const size_t nwords = 5 * ncol + 2 * ncell;
+    const int nsets = c.pipeline && jobs.size() > 1 ? 2 : 1;
+    uint64_t* pinned[2] = {nullptr, nullptr};
+    uint64_t* ptrs[2][RT_N_TALLIES];
+    for (int b = 0; b < nsets; ++b)
     {
-        host[t].resize(t < RT_ATMOS_DIRECT ? ncol : ncell);
-        ptrs[t] = host[t].data();
+        void* p = nullptr;
+        check(rt_host_alloc(nwords * sizeof(uint64_t), &p), "rt_host_alloc");
+        pinned[b] = static_cast<uint64_t*>(p);
+        size_t off = 0;
+        for (int t = 0; t < RT_N_TALLIES; ++t) { ptrs[b][t] = pinned[b] + off; off += t < RT_ATMOS_DIRECT ? ncol : ncell; }
     }
+    const auto count_of = [&](int t) { return t < RT_ATMOS_DIRECT ? ncol : ncell; };
 
-    for (const Job& job : jobs)
+    // What is left of a job once its counts are on the host: files, checkpoint, the reference's stdout lines.
+    struct Done { size_t job; int set; uint64_t first_id; double seconds; };
+    std::string writer_error;
+    const auto finish = [&](const Done& d)
     {
+        const Job& job = jobs[d.job];
+        try
+        {
+            if (sweep_z || sweep_a) mkdir(job.dir.c_str(), 0777);
+            // the two 3D absorption fields are all but 2 % of the bytes: one goes out on a thread of its own
+            std::string other_error;
+            std::thread other([&] {
+                try { save_binary(job.dir, kTallyNames[RT_ATMOS_DIFFUSE], ptrs[d.set][RT_ATMOS_DIFFUSE], count_of(RT_ATMOS_DIFFUSE)); }
+                catch (const std::exception& e) { other_error = e.what(); }
+            });
+            try
+            {
+                for (int t = 0; t < RT_ATMOS_DIFFUSE; ++t) save_binary(job.dir, kTallyNames[t], ptrs[d.set][t], count_of(t));
+            }
+            catch (...) { other.join(); throw; }
+            other.join();
+            if (!other_error.empty()) throw std::runtime_error(other_error);
+            Checkpoint k;
+            k.seed = c.seed; k.next_photon_id = d.first_id + n_photons;
+            k.itot = c.itot; k.jtot = c.jtot; k.ktot = c.ktot; k.launch_log2k = launch_log2k; k.launch_tile_log2 = launch_tile_log2;
+            k.zenith_deg = job.zen; k.azimuth_deg = job.azi; k.albedo = c.albedo; k.fixed_dot = c.fixed_dot;
+            write_checkpoint(job.dir, k);
+        }
+        catch (const std::exception& e) { writer_error = e.what(); }
+    };
+
+    std::thread writer;
+    bool warned_host_sum = false;
+    double trace_seconds = 0.;
+    const auto sweep0 = std::chrono::high_resolution_clock::now();
+    for (size_t jn = 0; jn < jobs.size(); ++jn)
+    {
+        const Job& job = jobs[jn];
+        const int set = (int)(jn % (size_t)nsets);
         const float zen = static_cast<float>(job.zen * (M_PI / 180.));   // raytracer_3d.cu:25
         const float azi = static_cast<float>(job.azi * (M_PI / 180.));   // raytracer_3d.cu:26
         uint64_t first_id = 0;
@@ -424,8 +475,15 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
             // the counts so far go to GPU 0 (raytracer_3d.cu:98-104 copies its host arrays up for this); the sum
             // over the GPUs below carries them into the total
             first_id = job.from.next_photon_id;
-            for (int t = 0; t < RT_N_TALLIES; ++t) load_tally(job.dir, kTallyNames[t], host[t].data(), host[t].size());
-            check(rt_upload_tallies(ctx[0], ptrs), "rt_upload_tallies");
+            std::vector<std::vector<uint64_t>> old(RT_N_TALLIES);
+            const uint64_t* oldp[RT_N_TALLIES];
+            for (int t = 0; t < RT_N_TALLIES; ++t)
+            {
+                old[t].resize(count_of(t));
+                load_tally(job.dir, kTallyNames[t], old[t].data(), old[t].size());
+                oldp[t] = old[t].data();
+            }
+            check(rt_upload_tallies(ctx[0], oldp), "rt_upload_tallies");
             std::cout << "Resuming " << job.dir << " at photon " << first_id << std::endl;
         }
         auto s0 = std::chrono::high_resolution_clock::now();
@@ -438,27 +496,79 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
             check(rt_trace(ctx[g], c.seed, begin, cnt), "rt_trace");
             begin += cnt;
         }
-        // the path's one exchange step: every GPU ends with the node total (RCCL over xGMI inside the library)
-        if (c.ngpus > 1) check(rt_allreduce(ctx.data(), c.ngpus), "rt_allreduce");
-        for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
-        auto s1 = std::chrono::high_resolution_clock::now();
-        const double dur = std::chrono::duration<double>(s1 - s0).count();
-        std::cout << "Duration: " << std::setprecision(5) << dur << " (s)" << std::endl;  // raytracer_3d.cu:169
-        std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons / dur << std::endl;
-
-        check(rt_download_tallies(ctx[0], ptrs), "rt_download_tallies");
-        if (sweep_z || sweep_a)
+        // the path's one exchange step: every GPU ends with the node total (RCCL over xGMI inside the library). Without
+        // RCCL (the library cannot be loaded, or a communicator cannot be made) the counts are summed on the host.
+        bool host_sum = false;
+        if (c.ngpus > 1 && rt_allreduce(ctx.data(), c.ngpus) != RT_OK)
         {
-            mkdir(job.dir.c_str(), 0777);
-            std::cout << "Writing " << job.dir << std::endl;
+            host_sum = true;
+            if (!warned_host_sum)
+                std::cerr << "Warning: " << rt_last_error() << "; summing the GPUs' counts on the host instead" << std::endl;
+            warned_host_sum = true;
         }
-        for (int t = 0; t < RT_N_TALLIES; ++t) save_binary(job.dir, kTallyNames[t], host[t].data(), host[t].size());
-        Checkpoint k;
-        k.seed = c.seed; k.next_photon_id = first_id + n_photons;
-        k.itot = c.itot; k.jtot = c.jtot; k.ktot = c.ktot; k.launch_log2k = launch_log2k; k.launch_tile_log2 = launch_tile_log2;
-        k.zenith_deg = job.zen; k.azimuth_deg = job.azi; k.albedo = c.albedo; k.fixed_dot = c.fixed_dot;
-        write_checkpoint(job.dir, k);
+        if (nsets == 1 || host_sum)
+        {
+            // the reference's order: wait for the kernel, then copy, then write (raytracer_3d.cu:165-203)
+            for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
+            const double dur = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - s0).count();
+            trace_seconds += dur;
+            std::cout << "Duration: " << std::setprecision(5) << dur << " (s)" << std::endl;  // raytracer_3d.cu:169
+            std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons / dur << std::endl;
+            if (writer.joinable()) writer.join();
+            check(rt_download_tallies(ctx[0], ptrs[set]), "rt_download_tallies");
+            if (host_sum)
+            {
+                std::vector<uint64_t> other(nwords);
+                uint64_t* op[RT_N_TALLIES];
+                size_t off = 0;
+                for (int t = 0; t < RT_N_TALLIES; ++t) { op[t] = other.data() + off; off += count_of(t); }
+                for (int g = 1; g < c.ngpus; ++g)
+                {
+                    check(rt_download_tallies(ctx[g], op), "rt_download_tallies");
+                    for (size_t w = 0; w < nwords; ++w) pinned[set][w] += other[w];
+                }
+            }
+            if (sweep_z || sweep_a) std::cout << "Writing " << job.dir << std::endl;
+            finish(Done{jn, set, first_id, dur});
+        }
+        else
+        {
+            // pipelined sweep: the copy of this job starts when its trace ends (an event, not a host wait), the context
+            // moves on to its other tally buffer, and the host goes straight on to enqueue the next job; a thread waits
+            // for the copy and writes the files. The set of host arrays is free again: its writer was joined two jobs ago.
+            int ticket = 0;
+            check(rt_download_tallies_async(ctx[0], ptrs[set], &ticket), "rt_download_tallies_async");
+            check(rt_swap_tally_buffer(ctx[0]), "rt_swap_tally_buffer");
+            if (writer.joinable()) writer.join();
+            if (sweep_z || sweep_a) std::cout << "Writing " << job.dir << std::endl;
+            writer = std::thread([&, jn, set, first_id, ticket, s0]
+            {
+                if (rt_download_wait(ctx[0], ticket) != RT_OK) { writer_error = rt_last_error(); return; }
+                finish(Done{jn, set, first_id, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - s0).count()});
+            });
+        }
+        if (!writer_error.empty()) break;
     }
+    if (writer.joinable()) writer.join();
+    if (!writer_error.empty()) die(writer_error);
+    for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
+    const double sweep_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - sweep0).count();
+    if (nsets == 2)
+    {
+        // one line per sweep in place of one per job (a job's end is not waited for on the host)
+        std::cout << "Duration: " << std::setprecision(5) << sweep_s << " (s)" << std::endl;
+        std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons * (double)jobs.size() / sweep_s << std::endl;
+    }
+    // machine-readable summary of the run ("metrics/logging"): one JSON object on the last line
+    std::cout << "{\"photons_per_job\": " << n_photons << ", \"jobs\": " << jobs.size() << ", \"gpus\": " << c.ngpus
+              << ", \"grid\": [" << c.itot << ", " << c.jtot << ", " << c.ktot << "], \"launch_log2k\": " << launch_log2k
+              << ", \"launch_tile_log2\": " << launch_tile_log2 << ", \"seed\": " << c.seed
+              << ", \"pipeline\": " << (nsets == 2 ? "true" : "false") << std::setprecision(9)
+              << ", \"sweep_seconds\": " << sweep_s << ", \"end_to_end_photons_per_s\": "
+              << (double)n_photons * (double)jobs.size() / sweep_s;
+    if (nsets == 1) std::cout << ", \"trace_seconds\": " << trace_seconds;
+    std::cout << "}" << std::endl;
+    for (int b = 0; b < nsets; ++b) rt_host_free(pinned[b]);
     for (int g = 0; g < c.ngpus; ++g) rt_destroy(ctx[g]);
 }
 } // namespace drv

@@ -124,11 +124,12 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: the whole number of
  *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or sorted
  *                    or the grid fits the Infinity Cache, else 8, 8, 4 unmerged)
- *   "levels"         supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
- *                    each crossed as one majorant region, wherever (majorant - mean extinction) * edge length
- *                    <= "merge_tau_milli" / 1000 — the optical depth of null collisions a crossing photon would
- *                    meet (levels = 0: one region per supervoxel; defaults -1 = automatic, 5 or 0 as for the
- *                    supervoxel size, and 1000)
+ *   "levels"         supervoxels are merged bottom-up into aligned boxes of up to 2^levels supervoxels per edge -- each
+ *                    axis on its own: cubes where the field is homogeneous all around, tall columns of clear air
+ *                    between clouds, flat layers under them -- each crossed as one majorant region, wherever
+ *                    (majorant - mean extinction) * 6 V / S of the box <= "merge_tau_milli" / 1000 -- the optical
+ *                    depth of null collisions a crossing photon would meet (levels = 0: one region per supervoxel;
+ *                    defaults -1 = automatic, 5 or 0 as for the supervoxel size, and 1000)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change; they steer the
@@ -213,6 +214,30 @@ int rt_synchronize(rt_context* ctx);
  * (copy_from_gpu, raytracer_3d.cu:174-180.) Synchronises first. */
 int rt_download_tallies(rt_context* ctx, uint64_t* const out[RT_N_TALLIES]);
 
+/* The same copy without blocking the host or the context's stream: the seven arrays leave the context's CURRENT tally
+ * buffer over a copy stream of the library, behind everything enqueued on the context's stream so far, and *ticket
+ * (0 or 1, alternating) names the copy for rt_download_wait. With host arrays from rt_host_alloc (pinned) the copy
+ * runs beside whatever the context's stream does next -- with rt_swap_tally_buffer, the next job's trace: the zenith
+ * sweep of the io flow (raytracer_3d_io.cu:174-212 copies seven arrays and writes seven files per run, strictly
+ * after its kernel) then hides download and file writes behind the next run's trace. Pageable host arrays work too
+ * (the copy is then staged by the runtime). At most two copies are in flight: a third call first waits for the one
+ * that used its ticket. */
+int rt_download_tallies_async(rt_context* ctx, uint64_t* const out[RT_N_TALLIES], int* ticket);
+
+/* Blocks until the copy `ticket` has arrived in its host arrays. */
+int rt_download_wait(rt_context* ctx, int ticket);
+
+/* Switches the context to its second tally buffer (allocated and zeroed at the first call; the context must own its
+ * tallies), in stream order: launches already enqueued keep the buffer they were given, later ones (rt_reset_tallies,
+ * rt_trace, downloads) use the other -- and wait on the device, not on the host, for a download that still reads it.
+ * No counterpart in the reference (one buffer, one run). */
+int rt_swap_tally_buffer(rt_context* ctx);
+
+/* Pinned host memory for rt_download_tallies_async / rt_upload_optics (hipHostMalloc / hipHostFree), so that a host
+ * program without HIP headers -- the C++ drivers -- can give the library buffers that DMA runs to directly. */
+int rt_host_alloc(size_t bytes, void** out);
+int rt_host_free(void* p);
+
 /* Adds caller-provided counts into the device tallies (restart: raytracer_3d.cu:98-104 copies
  * the host arrays up "to enable restarts later"). */
 int rt_upload_tallies(rt_context* ctx, const uint64_t* const in[RT_N_TALLIES]);
@@ -260,10 +285,10 @@ int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
  * equal nck*ncj*nci of rt_get_slabs). Test/diagnostic access; no counterpart in the reference. */
 int rt_get_majorants(rt_context* ctx, float* out_pairs, size_t n_pairs);
 
-/* The region level of every supervoxel, [ck][cj][ci] (n must equal nck*ncj*nci): its majorant region is the
- * aligned cube of 2^level supervoxels per edge around it; rt_get_majorants returns the region's pair.
- * Test/diagnostic access; no counterpart in the reference. */
-int rt_get_region_levels(rt_context* ctx, uint8_t* out, size_t n);
+/* The region levels of every supervoxel, [ck][cj][ci] (n must equal nck*ncj*nci), lx | ly << 3 | lz << 6: its majorant
+ * region is the aligned box of 2^lx x 2^ly x 2^lz supervoxels around it (clipped at the grid); rt_get_majorants
+ * returns the region's pair. Test/diagnostic access; no counterpart in the reference. */
+int rt_get_region_levels(rt_context* ctx, uint16_t* out, size_t n);
 
 /* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
  * but RT_EV_ABORT). Synchronises first. */

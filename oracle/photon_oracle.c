@@ -240,10 +240,10 @@ typedef struct
                    a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
                    surface reflects to (+-mu, 0, sqrt(1-mu^2)) (raytracer.cpp:280-282); the signs are the top
                    bit of the draw that is the azimuth in 3D. Meant for jtot = 1 and azimuth = 0. */
-    int levels; /* supervoxels are merged bottom-up into aligned cubes of up to 2^levels supervoxels per edge,
-                   each crossed as ONE majorant region, wherever that wastes little (0 = no merging) */
-    float merge_tau; /* a cube is merged when (majorant - mean extinction) * edge length <= merge_tau: the
-                        optical depth of null collisions a photon crossing it would meet. Clear air merges
+    int levels; /* supervoxels are merged bottom-up into aligned boxes of up to 2^levels supervoxels per edge (each
+                   axis on its own), each crossed as ONE majorant region, wherever that wastes little (0 = no merging) */
+    float merge_tau; /* two buddy regions are merged when (majorant - mean extinction) * 6 V / S <= merge_tau: the
+                        optical depth of null collisions a photon crossing the box would meet. Clear air merges
                         at any size, homogeneous cloud too; cloud edges keep their fine supervoxels. */
     int launch_tile_log2; /* stratified launch: 0 = columns in row-major order; T > 0 = columns counted tile by tile
                              (tiles of 2^T x 2^T columns, row-major inside, tiles row by row; itot and jtot are
@@ -267,8 +267,8 @@ typedef struct
     float hx, hy, hz;   /* supervoxel edge lengths */
     float* maj;         /* nck*ncj*nci pairs {M, 1/M} of the REGION a supervoxel belongs to; owned,
                            freed by oracle_free_slabs */
-    unsigned char* lvl; /* nck*ncj*nci region levels: the supervoxel's region is the aligned cube of 2^lvl
-                           supervoxels per edge that contains it (clipped at the grid) */
+    uint16_t* lvl;      /* nck*ncj*nci region levels lx | ly << 3 | lz << 6: the supervoxel's region is the aligned box of
+                           2^lx x 2^ly x 2^lz supervoxels that contains it (clipped at the grid) */
 } oracle_slabs_t;
 
 void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->lvl); s->lvl = NULL; }
@@ -283,64 +283,91 @@ static inline float majorant_reciprocal(float m)
     return fminf(1.0f / m, FLT_MAX);
 }
 
-/* Region hierarchy over the supervoxel grid, built bottom-up: the aligned cube of 2^L supervoxels per edge
- * (clipped at the grid) becomes one region if all its members are regions of level L-1 and
- * (M - mean k_tot) * (2^L * edge) <= tau, with M the maximum and mean the volume mean of the extinction
- * over the cube. maj: pairs {M, 1/M} per supervoxel in, per region out. ksum/kcnt: sum (double, cells in
- * k, j, i order) and number of cells per supervoxel. All arithmetic of the criterion is double, in a
- * fixed order, so that the library's copy of this routine decides identically. */
+/* Majorant regions over the supervoxel grid: aligned BOXES of 2^lx x 2^ly x 2^lz supervoxels (clipped at the grid),
+ * grown bottom-up by merging buddies. Sweep s = 0, 1, 2, ... works on axis s mod 3 (x, y, z in turn) at level
+ * t = s / 3: a region whose level along that axis is t and whose origin has bit t of that coordinate clear merges
+ * with its buddy -- the region of the same shape that starts 2^t supervoxels further along the axis -- if
+ * (M - mean k_tot) * len <= tau, with M the maximum and mean the volume mean of the extinction over both, and
+ * len = 6 V / S of the merged box (its edge if it is a cube; three times its thickness if it is a wide slab): the
+ * optical depth of null collisions a crossing photon meets on average, up to the factor 2/3 of the mean chord.
+ * A buddy that lies outside the grid merges trivially (the clipped region only moves up a level, so that it can
+ * still meet its buddies along the other axes). Growing the three axes in turn gives cubes where the field is
+ * homogeneous around them -- clear air and the inside of a cloud -- and boxes that go on along one or two axes
+ * where the others are blocked: tall columns of clear air between clouds, flat layers under and over them.
+ * maj: pairs {M, 1/M} per supervoxel in, per region out. ksum/kcnt: sum (double, cells in k, j, i order) and number
+ * of cells per supervoxel. The criterion is evaluated in double, sums are added lower region first, regions are
+ * visited in index order: the library's copy of this routine must decide identically.
+ * lvl[e] = lx | ly << 3 | lz << 6 of the region supervoxel e belongs to. */
 static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, const double* ksum, const int* kcnt,
-                          float edge, float tau, unsigned char* lvl)
+                          float hx, float hy, float hz, float tau, uint16_t* lvl)
 {
     const size_t n = (size_t)nci * ncj * nck;
-    memset(lvl, 0, n);
-    for (int L = 1; L <= max_level; ++L)
+    const int dims[3] = {nci, ncj, nck};
+    const double h[3] = {(double)hx, (double)hy, (double)hz};
+    memset(lvl, 0, n * sizeof(uint16_t));
+    float* rmax = (float*)malloc(sizeof(float) * n);        /* per region, kept at its origin supervoxel */
+    double* rsum = (double*)malloc(sizeof(double) * n);
+    long long* rcnt = (long long*)malloc(sizeof(long long) * n);
+    for (size_t e = 0; e < n; ++e) { rmax[e] = maj[2 * e]; rsum[e] = ksum[e]; rcnt[e] = kcnt[e]; }
+    for (int sweep = 0; sweep < 3 * max_level; ++sweep)
     {
-        const int sz = 1 << L;
-        for (int bk = 0; bk < nck; bk += sz)
-            for (int bj = 0; bj < ncj; bj += sz)
-                for (int bi = 0; bi < nci; bi += sz)
+        const int axis = sweep % 3, t = sweep / 3;
+        for (int k = 0; k < nck; ++k)
+            for (int j = 0; j < ncj; ++j)
+                for (int i = 0; i < nci; ++i)
                 {
-                    const int k1 = bk + sz < nck ? bk + sz : nck, j1 = bj + sz < ncj ? bj + sz : ncj,
-                              i1 = bi + sz < nci ? bi + sz : nci;
-                    int ok = 1;
-                    float m = 0.0f;
-                    double sum = 0.0;
-                    long long cnt = 0;
-                    for (int k = bk; k < k1 && ok; ++k)
-                        for (int j = bj; j < j1 && ok; ++j)
-                            for (int i = bi; i < i1; ++i)
-                            {
-                                const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                if (lvl[e] != L - 1) { ok = 0; break; }
-                                if (maj[2 * e] > m) m = maj[2 * e];
-                                sum += ksum[e];
-                                cnt += kcnt[e];
-                            }
-                    if (!ok) continue;
-                    if (((double)m - sum / (double)cnt) * (double)edge * (double)sz > (double)tau) continue;
-                    for (int k = bk; k < k1; ++k)
-                        for (int j = bj; j < j1; ++j)
-                            for (int i = bi; i < i1; ++i)
-                            {
-                                const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                lvl[e] = (unsigned char)L;
-                                maj[2 * e] = m;
-                                maj[2 * e + 1] = majorant_reciprocal(m);
-                            }
+                    const size_t e = ((size_t)k * ncj + j) * nci + i;
+                    const int l[3] = {lvl[e] & 7, (lvl[e] >> 3) & 7, (lvl[e] >> 6) & 7};
+                    const int o[3] = {i, j, k};
+                    /* origins of regions at level t along the axis, lower buddy only */
+                    if (l[axis] != t || (i & ((1 << l[0]) - 1)) || (j & ((1 << l[1]) - 1)) || (k & ((1 << l[2]) - 1))) continue;
+                    if ((o[axis] >> t) & 1) continue;
+                    int bo[3] = {i, j, k};
+                    bo[axis] += 1 << t;
+                    int hi[3];          /* clipped end of the merged box */
+                    for (int d = 0; d < 3; ++d)
+                    {
+                        const int len = 1 << (l[d] + (d == axis ? 1 : 0));
+                        hi[d] = o[d] + len < dims[d] ? o[d] + len : dims[d];
+                    }
+                    if (bo[axis] < dims[axis])
+                    {
+                        const size_t be = ((size_t)bo[2] * ncj + bo[1]) * nci + bo[0];
+                        if (lvl[be] != lvl[e]) continue;            /* the buddy is not a region of the same shape */
+                        const float m = rmax[be] > rmax[e] ? rmax[be] : rmax[e];
+                        const double sum = rsum[e] + rsum[be];
+                        const long long cnt = rcnt[e] + rcnt[be];
+                        const double ex = (double)(hi[0] - o[0]) * h[0], ey = (double)(hi[1] - o[1]) * h[1],
+                                     ez = (double)(hi[2] - o[2]) * h[2];
+                        const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
+                        if (((double)m - sum / (double)cnt) * len > (double)tau) continue;
+                        rmax[e] = m; rsum[e] = sum; rcnt[e] = cnt;
+                    }
+                    const uint16_t nl = (uint16_t)(lvl[e] + (1u << (3 * axis)));
+                    for (int kk = k; kk < hi[2]; ++kk)
+                        for (int jj = j; jj < hi[1]; ++jj)
+                            for (int ii = i; ii < hi[0]; ++ii)
+                                lvl[((size_t)kk * ncj + jj) * nci + ii] = nl;
                 }
     }
-    /* The level rides in the three low mantissa bits of M, rounded UP to make room (still a majorant, larger
-     * by < 1e-6), and 1/M is taken from the packed value: one 8-byte table entry tells a traverse step
-     * everything about its region. */
-    for (size_t e = 0; e < n; ++e)
-    {
-        uint32_t bits;
-        memcpy(&bits, &maj[2 * e], 4);
-        bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
-        memcpy(&maj[2 * e], &bits, 4);
-        maj[2 * e + 1] = majorant_reciprocal(maj[2 * e]);
-    }
+    /* every supervoxel takes its region's majorant (kept at the region's origin). The levels ride in the nine low
+     * mantissa bits of M, rounded UP to make room (still a majorant, larger by < 2^-14 of itself), and 1/M is taken
+     * from the packed value: one 8-byte table entry tells a traverse step everything about its region. */
+    for (int k = 0; k < nck; ++k)
+        for (int j = 0; j < ncj; ++j)
+            for (int i = 0; i < nci; ++i)
+            {
+                const size_t e = ((size_t)k * ncj + j) * nci + i;
+                const int lx = lvl[e] & 7, ly = (lvl[e] >> 3) & 7, lz = (lvl[e] >> 6) & 7;
+                const size_t oe = ((size_t)((k >> lz) << lz) * ncj + ((j >> ly) << ly)) * nci + ((i >> lx) << lx);
+                uint32_t bits;
+                const float m = rmax[oe];
+                memcpy(&bits, &m, 4);
+                bits = ((bits + 511u) & ~511u) | (uint32_t)lvl[e];
+                memcpy(&maj[2 * e], &bits, 4);
+                maj[2 * e + 1] = majorant_reciprocal(maj[2 * e]);
+            }
+    free(rmax); free(rsum); free(rcnt);
 }
 
 /* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
@@ -405,7 +432,7 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         out->gslab = g; out->nci = nci; out->ncj = ncj; out->nck = nck;
         out->hx = (float)sc->sx * sc->dx; out->hy = (float)sc->sy * sc->dy; out->hz = (float)sc->sz * sc->dz;
         out->maj = (float*)malloc(sizeof(float) * 2 * (size_t)nci * ncj * nck);
-        out->lvl = (unsigned char*)malloc((size_t)nci * ncj * nck);
+        out->lvl = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)nci * ncj * nck);
         double* ksum = (double*)malloc(sizeof(double) * (size_t)nci * ncj * nck);
         int* kcnt = (int*)malloc(sizeof(int) * (size_t)nci * ncj * nck);
         for (int ck = 0; ck < nck; ++ck)
@@ -434,8 +461,8 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
                     ksum[e] = sum;
                     kcnt[e] = cnt;
                 }
-        build_regions(nci, ncj, nck, sc->levels > 0 ? sc->levels : 0, out->maj, ksum, kcnt, out->hx, sc->merge_tau,
-                      out->lvl);
+        build_regions(nci, ncj, nck, sc->levels > 0 ? sc->levels : 0, out->maj, ksum, kcnt, out->hx, out->hy, out->hz,
+                      sc->merge_tau, out->lvl);
         free(ksum); free(kcnt);
     }
 }
@@ -564,19 +591,20 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         /* ---- traverse one majorant region ---- */
         const int gridded = slab == g;
         float M, invM, tx, ty, tz, fz;
-        /* the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck), clipped at the grid */
-        int L = 0;
+        /* the region: the aligned box of 2^Lx x 2^Ly x 2^Lz supervoxels around (ci, cj, ck), clipped at the grid */
+        int Lx = 0, Ly = 0, Lz = 0;
         size_t e = 0;
         if (gridded)
         {
             e = ((size_t)ck * ncj + cj) * nci + ci;
             uint32_t mbits;
             memcpy(&mbits, &sl->maj[2 * e], 4);
-            L = (int)(mbits & 7u);
+            Lx = (int)(mbits & 7u); Ly = (int)((mbits >> 3) & 7u); Lz = (int)((mbits >> 6) & 7u);
         }
-        const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
-        const int bx1 = bx0 + (1 << L) < nci ? bx0 + (1 << L) : nci, by1 = by0 + (1 << L) < ncj ? by0 + (1 << L) : ncj,
-                  bz1 = bz0 + (1 << L) < nck ? bz0 + (1 << L) : nck;
+        const int L = Lx | Ly | Lz;
+        const int bx0 = (ci >> Lx) << Lx, by0 = (cj >> Ly) << Ly, bz0 = (ck >> Lz) << Lz;
+        const int bx1 = bx0 + (1 << Lx) < nci ? bx0 + (1 << Lx) : nci, by1 = by0 + (1 << Ly) < ncj ? by0 + (1 << Ly) : ncj,
+                  bz1 = bz0 + (1 << Lz) < nck ? bz0 + (1 << Lz) : nck;
         const float xlo = (float)bx0 * hx, xhi = (bx1 == nci) ? xs : (float)bx1 * hx;
         const float ylo = (float)by0 * hy, yhi = (by1 == ncj) ? ys : (float)by1 * hy;
         const float fx = iux > 0.0f ? xhi : xlo, fy = iuy > 0.0f ? yhi : ylo;

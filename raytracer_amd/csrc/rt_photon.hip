@@ -574,10 +574,11 @@ rt_trace_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
-                    // the region: the aligned cube of 2^L supervoxels per edge around (ci, cj, ck)
-                    const int L = gridded ? (int)(__float_as_uint(mm.x) & 7u) : 0;
-                    const int bx0 = (ci >> L) << L, by0 = (cj >> L) << L, bz0 = (ck >> L) << L;
-                    const int bx1 = min(bx0 + (1 << L), a.nci), by1 = min(by0 + (1 << L), a.ncj), bz1 = min(bz0 + (1 << L), a.nck);
+                    // the region: the aligned box of 2^Lx x 2^Ly x 2^Lz supervoxels around (ci, cj, ck)
+                    const uint32_t lb = gridded ? __float_as_uint(mm.x) : 0u;
+                    const int Lx = (int)(lb & 7u), Ly = (int)((lb >> 3) & 7u), Lz = (int)((lb >> 6) & 7u), L = Lx | Ly | Lz;
+                    const int bx0 = (ci >> Lx) << Lx, by0 = (cj >> Ly) << Ly, bz0 = (ck >> Lz) << Lz;
+                    const int bx1 = min(bx0 + (1 << Lx), a.nci), by1 = min(by0 + (1 << Ly), a.ncj), bz1 = min(bz0 + (1 << Lz), a.nck);
                     // the face ahead on each axis: index of the cell face, then its coordinate
                     const int cfx = iux > 0.0f ? bx1 : bx0, cfy = iuy > 0.0f ? by1 : by0;
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
@@ -748,6 +749,9 @@ enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
 constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
 constexpr uint32_t kTickRounds = 1u << 21;
+#ifndef RT_AUTO_LEVELS
+#define RT_AUTO_LEVELS 5      // option "levels" = -1 on fine supervoxels: regions of up to 2^5 supervoxels per edge
+#endif
 #ifndef RT_FUSE_LAUNCH
 #define RT_FUSE_LAUNCH 1
 #endif
@@ -793,12 +797,13 @@ constexpr int kPoolBlock = 64;
                     if (STATS) ++ev_step; \
                     const float2 mm = (MM); \
                     __builtin_amdgcn_s_setprio(0); \
-                    const int L = HIER ? (int)(__float_as_uint(mm.x) & 7u) : 0; \
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
                     if (HIER) \
                     { \
-                        bx0 = (ci >> L) << L; by0 = (cj >> L) << L; bz0 = (ck >> L) << L; \
-                        bx1 = min(bx0 + (1 << L), a.nci); by1 = min(by0 + (1 << L), a.ncj); bz1 = min(bz0 + (1 << L), a.nck); \
+                        const uint32_t lb = __float_as_uint(mm.x); \
+                        const int Lx = (int)(lb & 7u), Ly = (int)((lb >> 3) & 7u), Lz = (int)((lb >> 6) & 7u); \
+                        bx0 = (ci >> Lx) << Lx; by0 = (cj >> Ly) << Ly; bz0 = (ck >> Lz) << Lz; \
+                        bx1 = min(bx0 + (1 << Lx), a.nci); by1 = min(by0 + (1 << Ly), a.ncj); bz1 = min(bz0 + (1 << Lz), a.nck); \
                     } \
                     const bool px = (IX) > 0.0f, py = (IY) > 0.0f, up = (IZ) > 0.0f; \
                     const int cfx = px ? bx1 : bx0, cfy = py ? by1 : by0, cfz = up ? bz1 : bz0; \
@@ -1193,13 +1198,19 @@ rt_trace_pool_kernel(const PoolArgs a)
                 const float rr = u01(w.x);
                 const float p_real = kt * inv_m;
                 const float s_scat = cr.y * p_real;
+                // the event index has 24 bits beside the ID's high byte: a photon that has used them all (2^24 events:
+                // a conservative scene over a white surface can keep one alive that long) is abandoned like one that
+                // runs into the step guard, instead of starting its random stream over at event 0
+                const bool worn = nev >= 0xffffffu;
                 const bool real = !on_surface && rr < p_real;
                 const bool scat = real && rr <= s_scat;
-                const bool absorbed = real && !scat;                    // absorption, raytracer_kernels.cu:551-566
+                const bool absorbed = real && !scat && !worn;           // absorption, raytracer_kernels.cu:551-566
                 const bool from_cloud = rr * kt < s_scat * cr.w;        // r/s < k_cloud/k_tot
-                const bool reflect = on_surface && rr <= cold_of(a)->albedo;
+                const bool reflect = on_surface && rr <= cold_of(a)->albedo && !worn;
                 const bool turn = scat || reflect;
-                const bool alive = !(absorbed || (on_surface && !reflect));
+                const bool alive = !(absorbed || (on_surface && !reflect) || worn);
+                if (__builtin_expect(worn, 0))
+                    tally_add(&cold_of(a)->events[RT_EV_ABORT]);
                 const float u_mu = u01(on_surface ? w.y : w.z), u_phi = u01(on_surface ? w.z : w.w);
                 if (STATS)
                 {
@@ -1515,6 +1526,7 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
                const float* __restrict__ asy,
                const float* __restrict__ ssa, float4* __restrict__ cells,
                unsigned int* __restrict__ lev_max_bits, unsigned int* __restrict__ lev_cloud,
+               unsigned int* __restrict__ invalid,      // [0] cells with values no tracer can use, [1] the lowest such cell
                uint32_t ncol, uint32_t itot, uint32_t nbi, uint32_t nbij, int chunks_per_level)
 {
     const int k = blockIdx.x / chunks_per_level;
@@ -1530,6 +1542,17 @@ rt_pack_kernel(const float* __restrict__ k_gas, const float* __restrict__ k_clou
         cells[brick_index(i, j, (uint32_t)k, nbi, nbij)] = make_float4(kt, ssa[base + c], as, cl);
         m = kt > m ? kt : m;
         cloudy |= as > 0.0f ? 1u : 0u;
+        // What the tracer cannot work with (the reference reads anything, raytracer_3d_io.cu:36-57): an extinction that is
+        // negative or not finite; where there is any extinction, a single-scattering albedo outside [0, 1] or an
+        // asymmetry outside (-1, 1) (a cell without extinction never collides: its ssa and asy are not looked at).
+        const float sa = ssa[base + c];
+        const bool ok_k = g >= 0.0f && g < __builtin_inff() && cl >= 0.0f && cl < __builtin_inff();
+        const bool ok_s = !(kt > 0.0f) || (sa >= 0.0f && sa <= 1.0f && __builtin_fabsf(as) < 1.0f);
+        if (__builtin_expect(!(ok_k && ok_s), 0))
+        {
+            atomicAdd(&invalid[0], 1u);
+            atomicMin(&invalid[1], (unsigned int)(base + c));
+        }
     }
     // wave reduction (64 lanes), then one atomic per wave
 #pragma unroll
@@ -1927,10 +1950,10 @@ struct rt_context
 
     float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
-    uint8_t* d_lvl = nullptr;         // region level per supervoxel (also the scratch of the cloud flags)
-    int levels = -1;                  // largest region: cubes of 2^levels supervoxels per edge (0 = no merging,
-                                      // -1 = automatic: 5 or 0)
-    int merge_tau_milli = 1000;       // merge criterion: (M - mean k_tot) * edge <= merge_tau_milli / 1000
+    uint16_t* d_lvl = nullptr;        // region levels lx | ly << 3 | lz << 6 per supervoxel
+    int levels = -1;                  // largest region: boxes of up to 2^levels supervoxels per edge (0 = no merging,
+                                      // -1 = automatic: RT_AUTO_LEVELS or 0)
+    int merge_tau_milli = 1000;       // merge criterion: (M - mean k_tot) * 6 V / S <= merge_tau_milli / 1000
     bool hier = false;                // any region larger than a supervoxel (selects the kernel variant)
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
@@ -1955,6 +1978,14 @@ struct rt_context
     size_t sort_capacity = 0;         // IDs the list holds
     unsigned long long* d_tallies = nullptr;
     bool owns_tallies = false;
+    // second tally buffer of the context (rt_swap_tally_buffer) and the asynchronous download (rt_download_tallies_async):
+    // a sweep traces job k+1 into one buffer while job k's counts leave the other over a copy stream
+    unsigned long long* d_tallies_alt = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t dl_ready = nullptr;            // recorded on the context's stream: the counts to download are complete
+    hipEvent_t dl_done[2] = {nullptr, nullptr};   // recorded on the copy stream per ticket: the download has left the buffer
+    const unsigned long long* dl_src[2] = {nullptr, nullptr};   // the device buffer each ticket reads
+    int dl_next = 0;
     unsigned long long* d_events = nullptr;
     uint32_t* d_wire = nullptr;       // nwords + 1 words: 32-bit image of the tallies for rt_allreduce (allocated on first use)
     bool wire32 = true;               // rt_allreduce sums 32-bit counts when every count allows it
@@ -2018,61 +2049,84 @@ void build_slabs(rt_context* c)
 
 // (Re)builds the majorant table on the device: supervoxels of the cloud slab (if the grid is
 // enabled and a cloud slab exists), followed by one {M, 1/M} entry per slab.
-// Region hierarchy over the supervoxel grid (host side of the pre-pass), built bottom-up: the aligned cube of
-// 2^L supervoxels per edge (clipped at the grid) becomes one region if all its members are regions of level
-// L-1 and (M - mean k_tot) * (2^L * edge) <= tau — the optical depth of null collisions a photon crossing it
-// would meet. Clear air merges at any size, homogeneous cloud too; cloud edges keep their fine supervoxels.
+// Majorant regions over the supervoxel grid (host side of the pre-pass): aligned BOXES of 2^lx x 2^ly x 2^lz
+// supervoxels (clipped at the grid), grown bottom-up by merging buddies. Sweep s works on axis s mod 3 (x, y, z in
+// turn) at level t = s / 3: a region whose level along that axis is t and whose origin has bit t of that coordinate
+// clear merges with its buddy -- the region of the same shape 2^t supervoxels further along the axis -- if
+// (M - mean k_tot) * len <= tau, len = 6 V / S of the merged box (its edge for a cube, three times the thickness of a
+// wide slab): the optical depth of null collisions a crossing photon meets. A buddy outside the grid merges
+// trivially. Growing the axes in turn gives cubes where the field is homogeneous all around (round 2's regions were
+// cubes only: 10.3 face crossings per photon on the LES grid) and boxes that go on along one or two axes where the
+// others are blocked: tall columns of clear air between clouds, flat layers under and over them.
 // maj: pairs {M, 1/M} per supervoxel in, per region out. Double arithmetic in a fixed order: the oracle's
-// copy of this routine must decide identically.
+// copy of this routine must decide identically. lvl[e] = lx | ly << 3 | lz << 6.
 void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>& maj, const std::vector<double>& ksum,
-                   const std::vector<int>& kcnt, float edge, float tau, std::vector<uint8_t>& lvl)
+                   const std::vector<int>& kcnt, float hx, float hy, float hz, float tau, std::vector<uint16_t>& lvl)
 {
-    std::fill(lvl.begin(), lvl.end(), (uint8_t)0);
-    for (int L = 1; L <= max_level; ++L)
+    const size_t n = (size_t)nci * ncj * nck;
+    const int dims[3] = {nci, ncj, nck};
+    const double h[3] = {(double)hx, (double)hy, (double)hz};
+    std::fill(lvl.begin(), lvl.end(), (uint16_t)0);
+    std::vector<float> rmax(n);              // per region, kept at its origin supervoxel
+    std::vector<double> rsum(ksum);
+    std::vector<long long> rcnt(n);
+    for (size_t e = 0; e < n; ++e) { rmax[e] = maj[e].x; rcnt[e] = kcnt[e]; }
+    const auto at = [&](int i, int j, int k) { return ((size_t)k * ncj + j) * nci + i; };
+    for (int sweep = 0; sweep < 3 * max_level; ++sweep)
     {
-        const int sz = 1 << L;
-        for (int bk = 0; bk < nck; bk += sz)
-            for (int bj = 0; bj < ncj; bj += sz)
-                for (int bi = 0; bi < nci; bi += sz)
+        const int axis = sweep % 3, t = sweep / 3;
+        for (int k = 0; k < nck; ++k)
+            for (int j = 0; j < ncj; ++j)
+                for (int i = 0; i < nci; ++i)
                 {
-                    const int k1 = std::min(bk + sz, nck), j1 = std::min(bj + sz, ncj), i1 = std::min(bi + sz, nci);
-                    bool ok = true;
-                    float m = 0.0f;
-                    double sum = 0.0;
-                    long long cnt = 0;
-                    for (int k = bk; k < k1 && ok; ++k)
-                        for (int j = bj; j < j1 && ok; ++j)
-                            for (int i = bi; i < i1; ++i)
-                            {
-                                const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                if (lvl[e] != L - 1) { ok = false; break; }
-                                if (maj[e].x > m) m = maj[e].x;
-                                sum += ksum[e];
-                                cnt += kcnt[e];
-                            }
-                    if (!ok) continue;
-                    if (((double)m - sum / (double)cnt) * (double)edge * (double)sz > (double)tau) continue;
-                    for (int k = bk; k < k1; ++k)
-                        for (int j = bj; j < j1; ++j)
-                            for (int i = bi; i < i1; ++i)
-                            {
-                                const size_t e = ((size_t)k * ncj + j) * nci + i;
-                                lvl[e] = (uint8_t)L;
-                                maj[e] = make_float2(m, majorant_reciprocal(m));
-                            }
+                    const size_t e = at(i, j, k);
+                    const int l[3] = {lvl[e] & 7, (lvl[e] >> 3) & 7, (lvl[e] >> 6) & 7};
+                    const int o[3] = {i, j, k};
+                    // origins of regions at level t along the axis, lower buddy only
+                    if (l[axis] != t || (i & ((1 << l[0]) - 1)) || (j & ((1 << l[1]) - 1)) || (k & ((1 << l[2]) - 1))) continue;
+                    if ((o[axis] >> t) & 1) continue;
+                    int bo[3] = {i, j, k};
+                    bo[axis] += 1 << t;
+                    int hi[3];          // clipped end of the merged box
+                    for (int d = 0; d < 3; ++d)
+                        hi[d] = std::min(o[d] + (1 << (l[d] + (d == axis ? 1 : 0))), dims[d]);
+                    if (bo[axis] < dims[axis])
+                    {
+                        const size_t be = at(bo[0], bo[1], bo[2]);
+                        if (lvl[be] != lvl[e]) continue;            // the buddy is not a region of the same shape
+                        const float m = rmax[be] > rmax[e] ? rmax[be] : rmax[e];
+                        const double sum = rsum[e] + rsum[be];
+                        const long long cnt = rcnt[e] + rcnt[be];
+                        const double ex = (double)(hi[0] - o[0]) * h[0], ey = (double)(hi[1] - o[1]) * h[1],
+                                     ez = (double)(hi[2] - o[2]) * h[2];
+                        const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
+                        if (((double)m - sum / (double)cnt) * len > (double)tau) continue;
+                        rmax[e] = m; rsum[e] = sum; rcnt[e] = cnt;
+                    }
+                    const uint16_t nl = (uint16_t)(lvl[e] + (1u << (3 * axis)));
+                    for (int kk = k; kk < hi[2]; ++kk)
+                        for (int jj = j; jj < hi[1]; ++jj)
+                            for (int ii = i; ii < hi[0]; ++ii)
+                                lvl[at(ii, jj, kk)] = nl;
                 }
     }
-    // The level rides in the three low mantissa bits of M, rounded UP to make room (still a majorant, larger
-    // by < 1e-6), and 1/M is taken from the packed value: one 8-byte table entry tells a traverse round
-    // everything about its region (a second table cost a second cache line per round).
-    for (size_t e = 0; e < maj.size(); ++e)
-    {
-        uint32_t bits;
-        memcpy(&bits, &maj[e].x, 4);
-        bits = ((bits + 7u) & ~7u) | (uint32_t)lvl[e];
-        memcpy(&maj[e].x, &bits, 4);
-        maj[e].y = majorant_reciprocal(maj[e].x);
-    }
+    // Every supervoxel takes its region's majorant (kept at the region's origin). The levels ride in the nine low
+    // mantissa bits of M, rounded UP to make room (still a majorant, larger by < 2^-14 of itself), and 1/M is taken
+    // from the packed value: one 8-byte table entry tells a traverse round everything about its region (a second
+    // table cost a second cache line per round).
+    for (int k = 0; k < nck; ++k)
+        for (int j = 0; j < ncj; ++j)
+            for (int i = 0; i < nci; ++i)
+            {
+                const size_t e = at(i, j, k);
+                const int lx = lvl[e] & 7, ly = (lvl[e] >> 3) & 7, lz = (lvl[e] >> 6) & 7;
+                const float m = rmax[at((i >> lx) << lx, (j >> ly) << ly, (k >> lz) << lz)];
+                uint32_t bits;
+                memcpy(&bits, &m, 4);
+                bits = ((bits + 511u) & ~511u) | (uint32_t)lvl[e];
+                memcpy(&maj[e].x, &bits, 4);
+                maj[e].y = majorant_reciprocal(maj[e].x);
+            }
 }
 
 // workgroups of the launch sort's count and scatter passes (two of 1024 threads fit a CU)
@@ -2107,7 +2161,7 @@ int build_majorants(rt_context* c)
     const int sgx = c->sgx >= 0 ? c->sgx : (fine ? nearest(80.0, (double)c->dx) : 8),
               sgy = c->sgy >= 0 ? c->sgy : (fine ? nearest(80.0, (double)c->dy) : 8),
               sgz = c->sgz >= 0 ? c->sgz : (fine ? nearest(50.0, (double)c->dz) : 4);
-    const int levels = c->levels >= 0 ? c->levels : (fine ? 5 : 0);
+    const int levels = c->levels >= 0 ? c->levels : (fine ? RT_AUTO_LEVELS : 0);
     c->built_fine = fine;
     const int g = (s.k_lo >= 0 && sgx > 0 && sgy > 0 && sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
     s.gslab = g; s.nci = s.ncj = s.nck = 0; s.hx = s.hy = s.hz = 0.0f;
@@ -2129,7 +2183,7 @@ int build_majorants(rt_context* c)
         RT_HIP(hipMalloc(&c->d_maj, sizeof(float2) * (ncoarse + 3)));
         if (c->d_lvl) RT_HIP(hipFree(c->d_lvl));
         c->d_lvl = nullptr;
-        RT_HIP(hipMalloc(&c->d_lvl, ncoarse + 4));
+        RT_HIP(hipMalloc(&c->d_lvl, sizeof(uint16_t) * (ncoarse + 4)));
         c->maj_capacity = ncoarse + 3;
     }
     if (ncoarse)
@@ -2149,7 +2203,7 @@ int build_majorants(rt_context* c)
         std::vector<float2> h_maj(ncoarse);
         std::vector<double> h_ksum(ncoarse);
         std::vector<int> h_kcnt(ncoarse);
-        std::vector<uint8_t> h_lvl(ncoarse);
+        std::vector<uint16_t> h_lvl(ncoarse);
         if (e == hipSuccess) e = hipMemcpyAsync(h_maj.data(), c->d_maj, sizeof(float2) * ncoarse, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_ksum.data(), d_ksum, sizeof(double) * ncoarse, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_kcnt.data(), d_kcnt, sizeof(int) * ncoarse, hipMemcpyDeviceToHost, c->stream);
@@ -2157,12 +2211,12 @@ int build_majorants(rt_context* c)
         if (d_ksum) (void)hipFree(d_ksum);
         if (d_kcnt) (void)hipFree(d_kcnt);
         RT_HIP(e);
-        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_ksum, h_kcnt, s.hx,
+        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_ksum, h_kcnt, s.hx, s.hy, s.hz,
                       (float)((double)c->merge_tau_milli / 1000.0), h_lvl);
         c->hier = false;
         for (size_t i = 0; i < ncoarse && !c->hier; ++i) c->hier = h_lvl[i] > 0;
         RT_HIP(hipMemcpyAsync(c->d_maj, h_maj.data(), sizeof(float2) * ncoarse, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(hipMemcpyAsync(c->d_lvl, h_lvl.data(), ncoarse, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(hipMemcpyAsync(c->d_lvl, h_lvl.data(), sizeof(uint16_t) * ncoarse, hipMemcpyHostToDevice, c->stream));
         RT_HIP(hipStreamSynchronize(c->stream));
     }
     float2 slab_m[3];
@@ -2178,18 +2232,33 @@ int build_majorants(rt_context* c)
 int pack_from_device(rt_context* c, const float* d_gas, const float* d_cloud, const float* d_ssa, const float* d_asy)
 {
     unsigned int* d_lev = nullptr;
-    RT_HIP(hipMalloc(&d_lev, sizeof(unsigned int) * 2 * c->ktot));
-    RT_HIP(hipMemsetAsync(d_lev, 0, sizeof(unsigned int) * 2 * c->ktot, c->stream));
+    c->have_optics = false;
+    RT_HIP(hipMalloc(&d_lev, sizeof(unsigned int) * (2 * c->ktot + 2)));
+    RT_HIP(hipMemsetAsync(d_lev, 0, sizeof(unsigned int) * (2 * c->ktot + 1), c->stream));
+    RT_HIP(hipMemsetAsync(d_lev + 2 * c->ktot + 1, 0xff, sizeof(unsigned int), c->stream));
     int chunks = (int)((c->ncol + kBlock * 8 - 1) / (kBlock * 8));
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(rt_pack_kernel, dim3(c->ktot * chunks), dim3(kBlock), 0, c->stream,
-                       d_gas, d_cloud, d_asy, d_ssa, c->d_cells, d_lev, d_lev + c->ktot,
+                       d_gas, d_cloud, d_asy, d_ssa, c->d_cells, d_lev, d_lev + c->ktot, d_lev + 2 * c->ktot,
                        (uint32_t)c->ncol, (uint32_t)c->itot, c->nbi, c->nbij, chunks);
     RT_HIP(hipGetLastError());
-    std::vector<unsigned int> lev(2 * c->ktot);
-    RT_HIP(hipMemcpyAsync(lev.data(), d_lev, sizeof(unsigned int) * 2 * c->ktot, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned int> lev(2 * c->ktot + 2);
+    RT_HIP(hipMemcpyAsync(lev.data(), d_lev, sizeof(unsigned int) * (2 * c->ktot + 2), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
     RT_HIP(hipFree(d_lev));
+    if (lev[2 * c->ktot] != 0u)
+    {
+        // refused: the context is left without optics (a photon in such a cell would spin until the step guard)
+        const size_t cell = lev[2 * c->ktot + 1];
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* const src[4] = {d_gas, d_cloud, d_ssa, d_asy};
+        for (int f = 0; f < 4; ++f) RT_HIP(hipMemcpy(&v[f], src[f] + cell, sizeof(float), hipMemcpyDeviceToHost));
+        return fail(RT_ERR_ARG, "rt_upload_optics: %u cells hold optical properties the tracer cannot use (extinction negative "
+                                "or not finite; ssa outside [0,1] or |asy| >= 1 where there is extinction); first: cell "
+                                "i=%zu j=%zu k=%zu with k_ext_gas=%g k_ext_cloud=%g ssa=%g asy=%g", lev[2 * c->ktot],
+                    cell % (size_t)c->itot, (cell / (size_t)c->itot) % (size_t)c->jtot, cell / c->ncol,
+                    (double)v[0], (double)v[1], (double)v[2], (double)v[3]);
+    }
     c->lev_max.resize(c->ktot);
     c->lev_cloud.resize(c->ktot);
     for (int k = 0; k < c->ktot; ++k)
@@ -2243,7 +2312,9 @@ struct RcclApi
 constexpr int kNcclSum = 0, kNcclUint32 = 3, kNcclUint64 = 5;      // rccl.h: ncclSum, ncclUint32, ncclUint64
 std::mutex g_rccl_mutex;
 RcclApi g_rccl;
-std::vector<std::pair<std::vector<int>, std::vector<void*>>> g_comm_sets;   // device list -> communicators (kept)
+std::vector<std::pair<std::vector<int>, std::vector<void*>>> g_comm_sets;   // device list -> communicators: kept until the
+// process ends ON PURPOSE (ncclCommDestroy from a static destructor would run after the HIP runtime has begun to shut
+// down; the driver reclaims them with the process)
 
 int load_rccl()
 {
@@ -2328,7 +2399,14 @@ int allreduce_impl(rt_context* const ctx[], int n)
         }
         RT_NCCL(g_rccl.GroupStart());
         for (int g = 0; g < n; ++g)
-            RT_NCCL(g_rccl.AllReduce(ctx[g]->d_wire, ctx[g]->d_wire, nwords + 1, kNcclUint32, kNcclSum, (*comms)[g], ctx[g]->stream));
+        {
+            const int r = g_rccl.AllReduce(ctx[g]->d_wire, ctx[g]->d_wire, nwords + 1, kNcclUint32, kNcclSum, (*comms)[g], ctx[g]->stream);
+            if (r != 0)
+            {
+                (void)g_rccl.GroupEnd();        // never leave RCCL inside an open group
+                return fail(RT_ERR_HIP, "ncclAllReduce (32-bit counts, GPU %d) failed: %s", ctx[g]->device, g_rccl.GetErrorString(r));
+            }
+        }
         RT_NCCL(g_rccl.GroupEnd());
         uint32_t flag = 0;
         for (int g = 0; g < n; ++g)
@@ -2350,7 +2428,14 @@ int allreduce_impl(rt_context* const ctx[], int n)
     }
     RT_NCCL(g_rccl.GroupStart());
     for (int g = 0; g < n; ++g)
-        RT_NCCL(g_rccl.AllReduce(ctx[g]->d_tallies, ctx[g]->d_tallies, nwords, kNcclUint64, kNcclSum, (*comms)[g], ctx[g]->stream));
+    {
+        const int r = g_rccl.AllReduce(ctx[g]->d_tallies, ctx[g]->d_tallies, nwords, kNcclUint64, kNcclSum, (*comms)[g], ctx[g]->stream);
+        if (r != 0)
+        {
+            (void)g_rccl.GroupEnd();
+            return fail(RT_ERR_HIP, "ncclAllReduce (64-bit counts, GPU %d) failed: %s", ctx[g]->device, g_rccl.GetErrorString(r));
+        }
+    }
     RT_NCCL(g_rccl.GroupEnd());
     for (int g = 0; g < n; ++g)
     {
@@ -2849,7 +2934,11 @@ int rt_destroy(rt_context* c)
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_maj) (void)hipFree(c->d_maj);
     if (c->d_lvl) (void)hipFree(c->d_lvl);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
+    if (c->d_tallies_alt) (void)hipFree(c->d_tallies_alt);
+    if (c->dl_ready) (void)hipEventDestroy(c->dl_ready);
+    for (int t = 0; t < 2; ++t) if (c->dl_done[t]) (void)hipEventDestroy(c->dl_done[t]);
     if (c->d_events) (void)hipFree(c->d_events);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_sort) (void)hipFree(c->d_sort);
@@ -2958,7 +3047,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "levels"))
     {
-        if (value < -1 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,6]", value);
+        if (value < -1 || value > 7) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,7]", value);
         c->levels = (int)value;
         c->maj_dirty = true;
     }
@@ -3060,6 +3149,82 @@ int rt_download_tallies(rt_context* c, uint64_t* const out[RT_N_TALLIES])
     return RT_OK;
 }
 
+int rt_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return fail(RT_ERR_ARG, "rt_host_alloc: null pointer");
+    *out = nullptr;
+    RT_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RT_OK;
+}
+
+int rt_host_free(void* p)
+{
+    if (p) RT_HIP(hipHostFree(p));
+    return RT_OK;
+}
+
+int rt_download_tallies_async(rt_context* c, uint64_t* const out[RT_N_TALLIES], int* ticket)
+{
+    if (!c || !out || !ticket) return fail(RT_ERR_ARG, "rt_download_tallies_async: null argument");
+    for (int t = 0; t < RT_N_TALLIES; ++t)
+        if (!out[t]) return fail(RT_ERR_ARG, "rt_download_tallies_async: out[%d] is null", t);
+    RT_HIP(hipSetDevice(c->device));
+    if (!c->copy_stream)
+    {
+        RT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        RT_HIP(hipEventCreateWithFlags(&c->dl_ready, hipEventDisableTiming));
+        for (int t = 0; t < 2; ++t) RT_HIP(hipEventCreateWithFlags(&c->dl_done[t], hipEventDisableTiming));
+    }
+    const int tk = c->dl_next;
+    c->dl_next ^= 1;
+    // the ticket's earlier download (two calls ago) must have left its host arrays: the caller has waited for it or
+    // waits now (a host array may be the same one again)
+    RT_HIP(hipEventSynchronize(c->dl_done[tk]));
+    // behind everything enqueued on the context's stream so far, on a stream of its own: the next trace does not wait
+    RT_HIP(hipEventRecord(c->dl_ready, c->stream));
+    RT_HIP(hipStreamWaitEvent(c->copy_stream, c->dl_ready, 0));
+    size_t off = 0;
+    for (int t = 0; t < RT_N_TALLIES; ++t)
+    {
+        const size_t n = t < RT_ATMOS_DIRECT ? c->ncol : c->ncell;
+        RT_HIP(hipMemcpyAsync(out[t], c->d_tallies + off, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+        off += n;
+    }
+    RT_HIP(hipEventRecord(c->dl_done[tk], c->copy_stream));
+    c->dl_src[tk] = c->d_tallies;
+    *ticket = tk;
+    return RT_OK;
+}
+
+int rt_download_wait(rt_context* c, int ticket)
+{
+    if (!c || ticket < 0 || ticket > 1) return fail(RT_ERR_ARG, "rt_download_wait: bad argument");
+    if (!c->dl_done[ticket]) return fail(RT_ERR_STATE, "rt_download_wait: no download was started");
+    RT_HIP(hipSetDevice(c->device));
+    RT_HIP(hipEventSynchronize(c->dl_done[ticket]));
+    return RT_OK;
+}
+
+int rt_swap_tally_buffer(rt_context* c)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_swap_tally_buffer: null context");
+    if (!c->owns_tallies)
+        return fail(RT_ERR_STATE, "rt_swap_tally_buffer: the context accumulates into a caller-owned buffer (rt_bind_tally_buffer)");
+    RT_HIP(hipSetDevice(c->device));
+    if (!c->d_tallies_alt)
+    {
+        RT_HIP(hipMalloc(&c->d_tallies_alt, sizeof(unsigned long long) * c->nwords));
+        RT_HIP(hipMemsetAsync(c->d_tallies_alt, 0, sizeof(unsigned long long) * c->nwords, c->stream));
+    }
+    std::swap(c->d_tallies, c->d_tallies_alt);
+    // whatever is enqueued on the context's stream from now on (reset, trace) touches the new current buffer: it must
+    // not run ahead of a download that still reads that buffer
+    for (int t = 0; t < 2; ++t)
+        if (c->dl_done[t] && c->dl_src[t] == c->d_tallies)
+            RT_HIP(hipStreamWaitEvent(c->stream, c->dl_done[t], 0));
+    return RT_OK;
+}
+
 int rt_upload_tallies(rt_context* c, const uint64_t* const in[RT_N_TALLIES])
 {
     if (!c || !in) return fail(RT_ERR_ARG, "rt_upload_tallies: null argument");
@@ -3113,7 +3278,10 @@ int rt_bind_tally_buffer(rt_context* c, void* ptr, size_t n_words)
     if (c->owns_tallies && c->d_tallies)
     {
         RT_HIP(hipStreamSynchronize(c->stream));
+        if (c->copy_stream) RT_HIP(hipStreamSynchronize(c->copy_stream));
         RT_HIP(hipFree(c->d_tallies));
+        if (c->d_tallies_alt) RT_HIP(hipFree(c->d_tallies_alt));
+        c->d_tallies_alt = nullptr;
     }
     c->d_tallies = (unsigned long long*)ptr;
     c->owns_tallies = false;
@@ -3175,7 +3343,7 @@ int rt_get_majorants(rt_context* c, float* out_pairs, size_t n_pairs)
     return RT_OK;
 }
 
-int rt_get_region_levels(rt_context* c, uint8_t* out, size_t n)
+int rt_get_region_levels(rt_context* c, uint16_t* out, size_t n)
 {
     if (!c || !out) return fail(RT_ERR_ARG, "rt_get_region_levels: null argument");
     if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_region_levels: call rt_upload_optics first");
@@ -3187,7 +3355,7 @@ int rt_get_region_levels(rt_context* c, uint8_t* out, size_t n)
     }
     if (n != c->ncoarse)
         return fail(RT_ERR_ARG, "rt_get_region_levels: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n);
-    if (n) RT_HIP(hipMemcpy(out, c->d_lvl, n, hipMemcpyDeviceToHost));
+    if (n) RT_HIP(hipMemcpy(out, c->d_lvl, sizeof(uint16_t) * n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -80,6 +80,11 @@ def load_library():
         "rt_download_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
         "rt_upload_tallies": (C.c_int, [vp, C.POINTER(u64p)]),
         "rt_reset_tallies": (C.c_int, [vp]),
+        "rt_download_tallies_async": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(C.c_int)]),
+        "rt_download_wait": (C.c_int, [vp, C.c_int]),
+        "rt_swap_tally_buffer": (C.c_int, [vp]),
+        "rt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+        "rt_host_free": (C.c_int, [vp]),
         "rt_tally_device_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
         "rt_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
@@ -87,7 +92,7 @@ def load_library():
         "rt_tallies_widen": (C.c_int, [vp, vp, vp]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
         "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
-        "rt_get_region_levels": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_size_t]),
+        "rt_get_region_levels": (C.c_int, [vp, C.POINTER(C.c_uint16), C.c_size_t]),
         "rt_get_events": (C.c_int, [vp, u64p]),
         "rt_get_sched_stats": (C.c_int, [vp, u64p]),
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -220,6 +225,32 @@ class PhotonTracer:
         _check(self.lib.rt_download_tallies(self._h, ptrs))
         return out
 
+    def pinned_tallies(self):
+        """The seven arrays in ONE block of pinned host memory (rt_host_alloc): what tallies_async() copies into while the
+        GPU goes on. Returns (dict of numpy views, handle to pass to free_pinned)."""
+        p = C.c_void_p()
+        _check(self.lib.rt_host_alloc(self.nwords * 8, C.byref(p)))
+        block = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(self.nwords,))
+        return split_tally_words(block, self.itot, self.jtot, self.ktot), p
+
+    def free_pinned(self, handle):
+        _check(self.lib.rt_host_free(handle))
+
+    def tallies_async(self, out):
+        """Start the copy of the CURRENT tally buffer into `out` (dict of the seven arrays, ideally pinned_tallies())
+        behind everything enqueued so far, on the library's copy stream; returns the ticket for tallies_wait()."""
+        ptrs = (C.POINTER(C.c_uint64) * 7)(*[out[n].ctypes.data_as(C.POINTER(C.c_uint64)) for n in TALLY_NAMES])
+        ticket = C.c_int()
+        _check(self.lib.rt_download_tallies_async(self._h, ptrs, C.byref(ticket)))
+        return ticket.value
+
+    def tallies_wait(self, ticket):
+        _check(self.lib.rt_download_wait(self._h, int(ticket)))
+
+    def swap_tally_buffer(self):
+        """Later launches use the context's other tally buffer (in stream order; see rt_swap_tally_buffer)."""
+        _check(self.lib.rt_swap_tally_buffer(self._h))
+
     def add_tallies(self, tallies):
         arrs = [np.ascontiguousarray(tallies[n], dtype=np.uint64) for n in TALLY_NAMES]
         ptrs = (C.POINTER(C.c_uint64) * 7)(*[a.ctypes.data_as(C.POINTER(C.c_uint64)) for a in arrs])
@@ -253,14 +284,14 @@ class PhotonTracer:
         return out
 
     def region_levels(self):
-        """Region level of every supervoxel, uint8 [nck, ncj, nci] (or None): cloud-free supervoxels are merged
-        into aligned cubes of 2^level supervoxels per edge; majorants() holds the region's pair."""
+        """Region levels of every supervoxel, uint16 [nck, ncj, nci] (or None), lx | ly << 3 | lz << 6: supervoxels are
+        merged into aligned boxes of 2^lx x 2^ly x 2^lz supervoxels; majorants() holds the region's pair."""
         s = self.slabs()
         n = s.nci * s.ncj * s.nck
         if n == 0:
             return None
-        out = np.zeros((s.nck, s.ncj, s.nci), dtype=np.uint8)
-        _check(self.lib.rt_get_region_levels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n))
+        out = np.zeros((s.nck, s.ncj, s.nci), dtype=np.uint16)
+        _check(self.lib.rt_get_region_levels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16)), n))
         return out
 
     def launch_positions(self, seed, photon_id_begin, n):
@@ -337,14 +368,26 @@ def split_tally_words(words, itot, jtot, ktot):
 
 
 def save_tallies(tallies, directory="."):
-    """Write the seven ``<name>.bin`` files of raytracer_3d.cu:184-203 (uint64, truncating)."""
+    """Write the seven ``<name>.bin`` files of raytracer_3d.cu:184-203 (uint64, truncating). The two 3D absorption
+    fields are all but 2 % of the bytes: one of them goes out on a thread of its own."""
+    import threading
     os.makedirs(directory, exist_ok=True)
-    for n in TALLY_NAMES:
+    errors = []
+
+    def write(n):
         path = os.path.join(directory, n + ".bin")
         try:
             np.ascontiguousarray(tallies[n], dtype=np.uint64).tofile(path)
         except OSError as exc:
-            raise RuntimeError(f'Cannot write file "{n}.bin"') from exc
+            errors.append((n, exc))
+
+    other = threading.Thread(target=write, args=(TALLY_NAMES[-1],))
+    other.start()
+    for n in TALLY_NAMES[:-1]:
+        write(n)
+    other.join()
+    if errors:
+        raise RuntimeError(f'Cannot write file "{errors[0][0]}.bin"') from errors[0][1]
 
 
 def photon_balance(t) -> int:

@@ -36,7 +36,7 @@ class OracleSlabs(C.Structure):
                 ("inv_kmaj", C.c_float * 3), ("k_lo", C.c_int), ("k_hi", C.c_int),
                 ("sun", C.c_float * 3), ("gslab", C.c_int), ("nci", C.c_int), ("ncj", C.c_int), ("nck", C.c_int),
                 ("hx", C.c_float), ("hy", C.c_float), ("hz", C.c_float), ("maj", C.POINTER(C.c_float)),
-                ("lvl", C.POINTER(C.c_ubyte))]
+                ("lvl", C.POINTER(C.c_uint16))]
 
 
 _lib = None

@@ -255,3 +255,54 @@ def test_2d_driver_writes_what_plot_results_reads(tmp_path):
     balance = int(rows["toa_down"].sum()) - (int(rows["surface_down_direct"].sum()) + int(rows["surface_down_diffuse"].sum())
                                              - int(rows["surface_up"].sum()) + int(rows["toa_up"].sum()) + int(atmos.sum()))
     assert balance == 0                                                                       # plot_results.py:27-31
+
+
+def test_pipelined_sweep_writes_the_same_bytes_and_a_json_summary(tmp_path):
+    """BASELINE config 5: a zenith sweep traces job k+1 while job k's seven arrays come down over a
+    copy stream into pinned memory and a host thread writes its files (rt_download_tallies_async +
+    rt_swap_tally_buffer; raytracer_3d_io.cu:174-212 does the three strictly one after another). Every file of every
+    run -- tallies and checkpoints -- is byte-identical with --pipeline=0, and equal to the oracle; the last stdout
+    line is one JSON object (metrics/logging)."""
+    import json
+    sc = scenes.cumulus(48, 40, 30, 100.0, 100.0, 30.0, n_clouds=8, seed=9, z_base=240.0, z_top=600.0, name="sweep")
+    zens = (0, 15, 30, 45, 60, 75)
+    out = {}
+    for mode in ("1", "0"):
+        d = tmp_path / f"pipe{mode}"
+        d.mkdir()
+        sc.write(str(d))
+        r = subprocess.run([IO, "17", "--seed=12", f"--pipeline={mode}", "--zenith=" + ",".join(str(z) for z in zens)], cwd=d,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        summary = json.loads(r.stdout.splitlines()[-1])
+        assert summary["jobs"] == 6 and summary["photons_per_job"] == 1 << 17 and summary["pipeline"] == (mode == "1")
+        assert summary["grid"] == [48, 40, 30] and summary["end_to_end_photons_per_s"] > 0
+        assert sum(l.startswith("Duration: ") for l in r.stdout.splitlines()) == (1 if mode == "1" else 6)
+        out[mode] = d
+    for zen in zens:
+        sub = f"zenith_{zen:02d}"
+        for name in list(TALLY_NAMES) + ["checkpoint"]:
+            fn = name + ".bin" if name != "checkpoint" else name
+            assert open(out["1"] / sub / fn, "rb").read() == open(out["0"] / sub / fn, "rb").read(), (zen, name)
+        sc.zenith_deg = float(zen)
+        k, _ = __import__("raytracer_amd").choose_launch_order(sc.itot, sc.jtot, sc.ktot, 1 << 17)
+        want, _ = O.photon_oracle(sc, 12, 0, 1 << 17, launch_log2k=k)
+        got = _read(out["1"] / sub, sc)
+        for n in TALLY_NAMES:
+            assert np.array_equal(got[n], want[n]), (zen, n)
+    # resumed pipelined sweep == one run of twice the photons
+    d2 = tmp_path / "twice"
+    d2.mkdir()
+    sc.write(str(d2))
+    r = subprocess.run([IO, "17", "--seed=12", "--resume", "--zenith=" + ",".join(str(z) for z in zens)], cwd=out["1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([IO, "18", "--seed=12", "--launch=sobol", "--zenith=" + ",".join(str(z) for z in zens)], cwd=d2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ck = dict(l.split(" = ") for l in open(out["1"] / "zenith_00" / "checkpoint").read().splitlines() if " = " in l)
+    if ck["launch_log2k"] == "-2":
+        for zen in zens:
+            for name in TALLY_NAMES:
+                a = open(out["1"] / f"zenith_{zen:02d}" / (name + ".bin"), "rb").read()
+                assert a == open(d2 / f"zenith_{zen:02d}" / (name + ".bin"), "rb").read(), (zen, name)

@@ -63,6 +63,19 @@ elif what == "merge4":
         for tau in (250, 500, 750, 1000, 1250, 1500):
             o = dict(base, levels=lv, merge_tau_milli=tau, supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
             res.append((run(o, 3),) + sg + (lv, tau))
+elif what == "regions":
+    # anisotropic majorant regions (round 3): supervoxel size x largest level x merge criterion; with the events per photon
+    def events(o):
+        for k, v in o.items():
+            tr.set_option(k, v)
+        tr.set_option("stats", 1); tr.reset(); tr.trace(1, 0, n); tr.synchronize(); ev = tr.events(); tr.set_option("stats", 0)
+        return "steps %.2f coll %.2f trans %.2f" % (ev["steps"] / n, ev["collision_tests"] / n, ev["transition"] / n)
+    combos = os.environ.get("RT_TUNE_REGIONS", "3x3x2:5:1000,3x3x2:7:1000,3x3x2:7:500,3x3x2:7:2000,2x2x2:7:1000,2x2x1:7:1000,3x3x1:7:1000,4x4x2:7:1000")
+    for item in combos.split(","):
+        sgs, lv, tau = item.split(":")
+        sg = tuple(int(v) for v in sgs.split("x"))
+        o = dict(base, levels=int(lv), merge_tau_milli=int(tau), supergrid_x=sg[0], supergrid_y=sg[1], supergrid_z=sg[2])
+        res.append((run(o, 3), item, events(o)))
 elif what == "thl":
     for thl in (16, 24, 32, 40, 48, 64):
         o = dict(base, pool=128, th_launch=thl); res.append((run(o, 3), thl))
