@@ -278,6 +278,19 @@ int rt_allreduce(rt_context* const ctx[], int n);
 int rt_tallies_narrow(rt_context* ctx, const void* tallies, void* wire, int world_size);
 int rt_tallies_widen(rt_context* ctx, void* tallies, const void* wire);
 
+/* Multi-GPU jobs without the narrowing and widening passes over the absorption arrays (98 % of the tally words): while
+ * a wire (nwords + 1 uint32 words, the layout rt_tallies_narrow writes) is bound, rt_trace counts ABSORPTIONS straight
+ * into wire[word] as 32-bit words instead of into the 64-bit tally buffer (same word index; a photon is absorbed at
+ * most once, so no word can pass the photons traced since the last reset: rt_trace refuses to go beyond 2^32 - 1 of
+ * them, and the sum over ranks is safe while the job's photons over ALL ranks stay below 2^32 -- the caller's check).
+ * The five 2-D arrays stay 64-bit (a photon can bounce off the surface any number of times: their words are the ones
+ * the flag of rt_tallies_narrow guards). With the wire bound, rt_reset_tallies zeroes the 2-D arrays and the wire's
+ * absorption words (half the bytes), rt_tallies_narrow narrows the 2-D arrays only (40 MB instead of 3.3 GB of traffic
+ * on the 1024 x 1024 x 128 grid), and rt_tallies_widen -- needed only when the 64-bit result is read, not per job --
+ * always widens the absorption words and the 2-D words unless the flag is raised. wire = NULL unbinds. Pool kernel
+ * only. No counterpart in the reference (single GPU). */
+int rt_bind_atmos_wire(rt_context* ctx, void* wire, size_t n_words);
+
 /* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
 int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
 

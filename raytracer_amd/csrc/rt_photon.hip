@@ -200,6 +200,7 @@ struct ColdBlock
     uint32_t sob_a, sob_b, sob_tile_log2, sob_klog2;
     uint32_t sob_b0;              // (low word of the launch's first ID) >> (sob_a + sob_b): its first net of the block
     uint32_t sob_tinv[16];        // unknown ID bits a .. a+b-1 = XOR of sob_tinv[r] over the set bits r of the residual
+    uint32_t* atm32;              // rt_bind_atmos_wire: absorption counts go here as 32-bit words (same word index), or null
 };
 
 // The cold block through the constant address space: its contents do not change while the tracer runs (the kernel
@@ -1327,7 +1328,13 @@ rt_trace_pool_kernel(const PoolArgs a)
                     if ((slot >> 6) == (uint32_t)h) st = v;
                 }
                 if (active && st == PS_LAUNCH_TALLY)
-                    tally_add(&k->tallies[RW(0)]);
+                {
+                    // (multi-GPU jobs count absorptions straight into the 32-bit image that crosses xGMI: rt_bind_atmos_wire)
+                    if (uint32_t* const a32 = cb->atm32)
+                        __hip_atomic_fetch_add(a32 + RW(0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        tally_add(&k->tallies[RW(0)]);
+                }
             }
             const bool go = active && (uint32_t)lane < wave_left;
             if (active && ranges_dry < (uint32_t)kXcds)
@@ -1848,7 +1855,7 @@ __global__ void rt_add_u64_kernel(unsigned long long* __restrict__ dst, const un
 // could pass 2^32) raises the flag in wire[n]. Widen (after the sum, flag included): if no rank raised the flag
 // the sums replace the 64-bit tallies, otherwise those are left as they were for the caller's 64-bit fallback.
 __global__ void rt_narrow_kernel(const unsigned long long* __restrict__ tallies, uint32_t* __restrict__ wire, size_t n,
-                                 int guard_shift)
+                                 uint32_t* __restrict__ flag, int guard_shift)
 {
     uint32_t big = 0u;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1858,14 +1865,16 @@ __global__ void rt_narrow_kernel(const unsigned long long* __restrict__ tallies,
         wire[i] = (uint32_t)t;
     }
     if (__ballot(big != 0u) != 0ull && (threadIdx.x & 63) == 0)
-        atomicOr(&wire[n], 1u);
+        atomicOr(flag, 1u);
 }
 
-__global__ void rt_widen_kernel(unsigned long long* __restrict__ tallies, const uint32_t* __restrict__ wire, size_t n)
+// native_from: words from this index on were COUNTED in the wire (rt_bind_atmos_wire: the absorption arrays), so they
+// have no 64-bit original and are widened whatever the flag says; n for an ordinary wire
+__global__ void rt_widen_kernel(unsigned long long* __restrict__ tallies, const uint32_t* __restrict__ wire, size_t n,
+                                size_t native_from)
 {
-    if (wire[n] != 0u)
-        return;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    const size_t first = wire[n] != 0u ? native_from : 0;
+    for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         tallies[i] = (unsigned long long)wire[i];
 }
 
@@ -1988,6 +1997,8 @@ struct rt_context
     int dl_next = 0;
     unsigned long long* d_events = nullptr;
     uint32_t* d_wire = nullptr;       // nwords + 1 words: 32-bit image of the tallies for rt_allreduce (allocated on first use)
+    uint32_t* atm_wire = nullptr;     // rt_bind_atmos_wire: caller's wire whose absorption words the tracer counts into
+    uint64_t atm_photons = 0;         // photons traced into atm_wire since it was last zeroed (a word cannot pass this)
     bool wire32 = true;               // rt_allreduce sums 32-bit counts when every count allows it
     ColdBlock* d_cold = nullptr;
 
@@ -2360,7 +2371,11 @@ int launch_narrow(rt_context* c, const unsigned long long* tallies, uint32_t* wi
     int guard_shift = 32;
     for (int r = 1; r < world; r <<= 1) --guard_shift;       // R counts below 2^(32 - ceil(log2 R)) sum below 2^32
     RT_HIP(hipMemsetAsync(wire + c->nwords, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(rt_narrow_kernel, dim3(2048), dim3(256), 0, c->stream, tallies, wire, c->nwords, guard_shift);
+    // a wire the tracer counts its absorptions into holds those words already: only the five 2-D arrays are narrowed
+    // (a kernel over 40 MB instead of 3.3 GB on the 1024 x 1024 x 128 grid); the flag word sits at wire[nwords] either way
+    const size_t n = wire == c->atm_wire ? 5 * c->ncol : c->nwords;
+    hipLaunchKernelGGL(rt_narrow_kernel, dim3(n > (1u << 22) ? 2048 : 256), dim3(256), 0, c->stream, tallies, wire, n,
+                       wire + c->nwords, guard_shift);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -2413,7 +2428,7 @@ int allreduce_impl(rt_context* const ctx[], int n)
         {
             rt_context* c = ctx[g];
             RT_HIP(hipSetDevice(c->device));
-            hipLaunchKernelGGL(rt_widen_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_tallies, c->d_wire, nwords);
+            hipLaunchKernelGGL(rt_widen_kernel, dim3(2048), dim3(256), 0, c->stream, c->d_tallies, c->d_wire, nwords, nwords);
             RT_HIP(hipGetLastError());
         }
         for (int g = 0; g < n; ++g)
@@ -2548,6 +2563,15 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         ((c->itot & ((1 << c->launch_tile_log2) - 1)) != 0 || (c->jtot & ((1 << c->launch_tile_log2) - 1)) != 0))
         return fail(RT_ERR_ARG, "%s: option launch_tile_log2 = %d needs itot and jtot to be multiples of %d (grid %d x %d)", who,
                     c->launch_tile_log2, 1 << c->launch_tile_log2, c->itot, c->jtot);
+    if (c->atm_wire)
+    {
+        if (c->pool == 0)
+            return fail(RT_ERR_ARG, "%s: a bound absorption wire (rt_bind_atmos_wire) needs the pool kernel (pool > 0)", who);
+        if (count > 0xffffffffull - c->atm_photons)
+            return fail(RT_ERR_ARG, "%s: %llu photons on top of the %llu already counted into the bound 32-bit absorption wire "
+                                    "could overflow a word (reset the tallies, or unbind the wire)", who,
+                        (unsigned long long)count, (unsigned long long)c->atm_photons);
+    }
     if (noalloc)
     {
         if (c->pool == 0)
@@ -2560,6 +2584,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
     }
     RT_HIP(hipSetDevice(c->device));
     if (count == 0) { c->timed = false; return RT_OK; }
+    if (c->atm_wire) c->atm_photons += count;
     if (c->maj_dirty)
     {
         const int rc = build_majorants(c);
@@ -2625,6 +2650,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         for (int i = 0; i < 4; ++i) cb.zface[i] = sl.zface[i];
         cb.inv_xs = 1.0f / xs; cb.inv_ys = 1.0f / ys;
         cb.ncoarse = (uint32_t)c->ncoarse; cb.nslab = sl.nslab;
+        cb.atm32 = c->atm_wire;
 
         PoolArgs a;
         a.cells = c->d_cells; a.maj = c->d_maj; a.tallies = c->d_tallies;
@@ -3251,7 +3277,16 @@ int rt_reset_tallies(rt_context* c)
 {
     if (!c) return fail(RT_ERR_ARG, "rt_reset_tallies: null context");
     RT_HIP(hipSetDevice(c->device));
-    RT_HIP(hipMemsetAsync(c->d_tallies, 0, c->nwords * sizeof(uint64_t), c->stream));
+    if (c->atm_wire)
+    {
+        // the absorption counts live in the bound wire: zero the five 2-D arrays here and the wire's absorption words
+        // (half the bytes of the 64-bit arrays they stand for), and its flag
+        RT_HIP(hipMemsetAsync(c->d_tallies, 0, 5 * c->ncol * sizeof(uint64_t), c->stream));
+        RT_HIP(hipMemsetAsync(c->atm_wire + 5 * c->ncol, 0, (2 * c->ncell + 1) * sizeof(uint32_t), c->stream));
+        c->atm_photons = 0;
+    }
+    else
+        RT_HIP(hipMemsetAsync(c->d_tallies, 0, c->nwords * sizeof(uint64_t), c->stream));
     // the abort counter (last word) survives a reset: rt_synchronize reports and clears it
     RT_HIP(hipMemsetAsync(c->d_events, 0, RT_EV_ABORT * sizeof(uint64_t), c->stream));
     RT_HIP(hipMemsetAsync(c->d_events + RT_N_EVENTS, 0, RT_N_SCHED * sizeof(uint64_t), c->stream));
@@ -3288,6 +3323,20 @@ int rt_bind_tally_buffer(rt_context* c, void* ptr, size_t n_words)
     return RT_OK;
 }
 
+int rt_bind_atmos_wire(rt_context* c, void* wire, size_t n_words)
+{
+    if (!c) return fail(RT_ERR_ARG, "rt_bind_atmos_wire: null context");
+    if (wire)
+    {
+        if (n_words != c->nwords + 1)
+            return fail(RT_ERR_ARG, "rt_bind_atmos_wire: wire has %zu words, the grid needs %zu", n_words, c->nwords + 1);
+        if (((uintptr_t)wire & 3u) != 0) return fail(RT_ERR_ARG, "rt_bind_atmos_wire: wire not 4-byte aligned");
+    }
+    c->atm_wire = static_cast<uint32_t*>(wire);
+    c->atm_photons = 0;
+    return RT_OK;
+}
+
 int rt_allreduce(rt_context* const ctx[], int n)
 {
     return allreduce_impl(ctx, n);
@@ -3308,7 +3357,8 @@ int rt_tallies_widen(rt_context* c, void* tallies, const void* wire)
     if (((uintptr_t)wire & 3u) != 0 || ((uintptr_t)tallies & 7u) != 0) return fail(RT_ERR_ARG, "rt_tallies_widen: misaligned buffer");
     RT_HIP(hipSetDevice(c->device));
     hipLaunchKernelGGL(rt_widen_kernel, dim3(2048), dim3(256), 0, c->stream,
-                       tallies ? (unsigned long long*)tallies : c->d_tallies, (const uint32_t*)wire, c->nwords);
+                       tallies ? (unsigned long long*)tallies : c->d_tallies, (const uint32_t*)wire, c->nwords,
+                       wire == c->atm_wire ? 5 * c->ncol : c->nwords);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

@@ -84,13 +84,14 @@ class ShardedTracer:
     job's ONE all-reduce; result(handle) returns the buffer holding the node total. With `overlap` (default for
     nccl at world size > 1) two buffers alternate and the all-reduce is asynchronous: it runs beside the next
     step's trace, and a step waits only for the all-reduce that used its buffer two steps earlier. With `wire32`
-    the counts cross the wire as 32-bit words (narrow -> all-reduce -> widen); if any rank holds a count too large
-    for that (the narrowing kernel checks on the device, the flag is summed with the data) result() repeats the
-    exchange on the 64-bit buffer, which the widening kernel then has left untouched. `reserve_lds` caps the pool
+    the counts cross the wire as 32-bit words (narrow -> all-reduce; result() widens); if any rank holds a count too
+    large for that (the narrowing kernel checks on the device, the flag is summed with the data) result() repeats the
+    exchange on the 64-bit buffer, which the widening kernel then has left untouched. With `atmos32` (default) the
+    tracer counts absorptions straight into the wire, so only the five 2-D arrays are narrowed at all. `reserve_lds` caps the pool
     kernel at POOL_WAVES_BESIDE_A_COLLECTIVE waves per CU while overlapping (an experiment, see above: off)."""
 
     def __init__(self, tracer, device, group=None, overlap=None, wire32=True, force_collective=False,
-                 reserve_lds=False):
+                 reserve_lds=False, atmos32=True):
         import torch
         self.torch = torch
         self.tracer, self.group = tracer, group
@@ -107,6 +108,14 @@ class ShardedTracer:
         n = tracer.nwords
         self.tallies = [torch.zeros(n, dtype=torch.int64, device=self.device) for _ in range(nbuf)]
         self.wire = [torch.zeros(n + 1, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if self.wire32 else None
+        # With 32-bit counts on the wire the tracer adds its absorptions straight into the wire (rt_bind_atmos_wire: 98 %
+        # of the words need no narrowing pass, half the bytes to zero per job) for every job of fewer than 2^32 photons
+        # over all ranks -- a photon is absorbed once, so no absorption word, and no sum of one over the ranks, can
+        # wrap; the widening back to 64-bit counts is left to result(), the only reader (a bench that reads the last
+        # job's result pays for it once, not per step).
+        self.atmos32 = bool(atmos32) and self.wire32 and hasattr(tracer, "bind_atmos_wire")
+        self.native = [False] * nbuf          # this buffer's absorption counts live in its wire
+        self.widened = [True] * nbuf
         self.pending = [None] * nbuf
         self.exchanged = [False] * nbuf
         self.steps = 0
@@ -135,6 +144,9 @@ class ShardedTracer:
         tally = self.tallies[b]
         if len(self.tallies) > 1:
             self.tracer.bind_tally_tensor(tally)
+        if self.atmos32:
+            self.native[b] = total_photons < (1 << 32)
+            self.tracer.bind_atmos_wire(self.wire[b] if self.native[b] else None)
         self.tracer.reset()
         begin, count = self.span(total_photons, first_photon_id)
         if before_trace is not None:
@@ -143,6 +155,7 @@ class ShardedTracer:
         if after_trace is not None:
             after_trace()
         self.exchanged[b] = False
+        self.widened[b] = True
         if not self.collective:
             return b
         if self.stage_through_host:
@@ -163,8 +176,9 @@ class ShardedTracer:
         return b
 
     def _after_exchange(self, b):
-        if self.wire32:
-            self.tracer.widen_tallies(self.wire[b], self.tallies[b])
+        # (the sums are in the wire; result() widens them into the 64-bit buffer if anyone asks: a buffer that is only
+        # zeroed again two steps later is never widened)
+        self.widened[b] = not self.wire32
         self.exchanged[b] = True
 
     def _current_stream_id(self):
@@ -215,9 +229,16 @@ class ShardedTracer:
         import torch.distributed as dist
         self._finish(handle)
         tally = self.tallies[handle]
+        if self.wire32 and self.exchanged[handle] and not self.widened[handle]:
+            if self.atmos32:        # the widening kernel must know whether this wire holds native absorption counts
+                self.tracer.bind_atmos_wire(self.wire[handle] if self.native[handle] else None)
+            self.tracer.widen_tallies(self.wire[handle], tally)
+            self.widened[handle] = True
         self._host_wait(f"result of buffer {handle} (trace, all-reduce, widening)")
         if self.wire32 and self.exchanged[handle] and int(self.wire[handle][-1].item()) != 0:
-            # a count too large for 32 bits somewhere: every rank sees the same flag sum and repeats in 64 bits
-            dist.all_reduce(tally, op=dist.ReduceOp.SUM, group=self.group)
+            # a count too large for 32 bits somewhere: every rank sees the same flag sum and repeats in 64 bits -- the
+            # whole buffer, or the five 2-D arrays when the absorption counts were native to the wire (widened above)
+            part = tally[:5 * self.tracer.ncol] if (self.atmos32 and self.native[handle]) else tally
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
             self.wire[handle][-1] = 0       # done: a second result() must not add again
         return tally

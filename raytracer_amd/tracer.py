@@ -88,6 +88,7 @@ def load_library():
         "rt_tally_device_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "rt_bind_tally_buffer": (C.c_int, [vp, vp, C.c_size_t]),
         "rt_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "rt_bind_atmos_wire": (C.c_int, [vp, vp, C.c_size_t]),
         "rt_tallies_narrow": (C.c_int, [vp, vp, vp, C.c_int]),
         "rt_tallies_widen": (C.c_int, [vp, vp, vp]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
@@ -195,6 +196,18 @@ class PhotonTracer:
         """The summed 32-bit words back into the 64-bit tallies, unless the flag word says a rank refused."""
         dst = C.c_void_p(tally_tensor.data_ptr()) if tally_tensor is not None else None
         _check(self.lib.rt_tallies_widen(self._h, dst, C.c_void_p(wire_tensor.data_ptr())))
+
+    def bind_atmos_wire(self, wire_tensor):
+        """While an int32 device tensor of nwords + 1 elements is bound, absorptions are counted straight into it as
+        32-bit words (rt_bind_atmos_wire); None unbinds."""
+        if wire_tensor is None:
+            _check(self.lib.rt_bind_atmos_wire(self._h, None, 0))
+            self._atm_wire = None
+            return
+        if wire_tensor.numel() != self.nwords + 1 or wire_tensor.element_size() != 4 or not wire_tensor.is_contiguous():
+            raise RtError(f"wire tensor must be contiguous, 4-byte, {self.nwords + 1} elements")
+        _check(self.lib.rt_bind_atmos_wire(self._h, C.c_void_p(wire_tensor.data_ptr()), self.nwords + 1))
+        self._atm_wire = wire_tensor
 
     def prepare(self):
         """Build the majorant tables now, so that later trace() calls are pure asynchronous launches."""

@@ -74,39 +74,57 @@ class _CpuTracer:
     """Stand-in with PhotonTracer's interface as ShardedTracer uses it, on CPU tensors: the oracle traces, and
     narrow / widen restate rt_narrow_kernel / rt_widen_kernel (the GPU tests check the kernels themselves)."""
 
-    def __init__(self, scene, extra=0):
+    def __init__(self, scene, extra=0, atmos32=True):
         self.scene, self.nwords, self.tensor, self.extra = scene, 5 * scene.ncol + 2 * scene.ncell, None, extra
+        self.ncol, self.atm = scene.ncol, None
+        if atmos32:     # restates rt_bind_atmos_wire: absorptions counted straight into the wire's 32-bit words
+            self.bind_atmos_wire = self._bind_atmos_wire
 
     def bind_tally_tensor(self, t):
         self.tensor = t
 
+    def _bind_atmos_wire(self, wire):
+        self.atm = wire
+
     def reset(self):
-        self.tensor.zero_()
+        if self.atm is None:
+            self.tensor.zero_()
+        else:
+            self.tensor[:5 * self.ncol].zero_()
+            self.tensor[5 * self.ncol:] = -12345        # stale in this mode: nothing may read it before the widening
+            self.atm[5 * self.ncol:].zero_()
 
     def trace(self, seed, begin, count):
         t, _ = O.photon_oracle(self.scene, seed, begin, count, nthreads=1)
-        words = np.concatenate([t[n].ravel() for n in O.TALLY_NAMES]).view(np.int64)
-        self.tensor += torch.from_numpy(words.copy())
+        words = torch.from_numpy(np.concatenate([t[n].ravel() for n in O.TALLY_NAMES]).view(np.int64).copy())
+        n2 = 5 * self.ncol
+        if self.atm is None:
+            self.tensor += words
+        else:
+            self.tensor[:n2] += words[:n2]
+            self.atm[n2:-1] += words[n2:].to(torch.int32)
         self.tensor[3] += self.extra               # a count that may not fit 32 bits on the wire
 
     def narrow_tallies(self, wire, world, tally=None):
         t = tally if tally is not None else self.tensor
         guard = 32 - int(np.ceil(np.log2(world))) if world > 1 else 32
-        wire[:-1] = torch.from_numpy((t.numpy() & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
-        wire[-1] = int(bool(((t >> guard) != 0).any()))
+        n = 5 * self.ncol if wire is self.atm else self.nwords
+        wire[:n] = torch.from_numpy((t.numpy()[:n] & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
+        wire[-1] = int(bool(((t[:n] >> guard) != 0).any()))
 
     def widen_tallies(self, wire, tally=None):
         t = tally if tally is not None else self.tensor
-        if int(wire[-1]) == 0:
-            t.copy_(torch.from_numpy(wire[:-1].numpy().view(np.uint32).astype(np.int64)))
+        first = 0 if int(wire[-1]) == 0 else (5 * self.ncol if wire is self.atm else self.nwords)
+        t[first:] = torch.from_numpy(wire[first:-1].numpy().view(np.uint32).astype(np.int64))
 
 
-def _sharded_worker(rank, world, port, out_dir, overlap, wire32, extra):
+def _sharded_worker(rank, world, port, out_dir, overlap, wire32, extra, atmos32=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = scenes.tiny()
-    st = D.ShardedTracer(_CpuTracer(sc, extra if rank == 1 else 0), "cpu", overlap=overlap, wire32=wire32)
+    st = D.ShardedTracer(_CpuTracer(sc, extra if rank == 1 else 0, atmos32), "cpu", overlap=overlap, wire32=wire32)
     assert st.collective and st.overlap == overlap and st.wire32 == wire32 and len(st.tallies) == (2 if overlap else 1)
+    assert st.atmos32 == (wire32 and atmos32)
     jobs = [(31, 3001, 7), (32, 2000, 100000), (33, 4099, 0)]          # (seed, photons, first id)
     handles = []
     for k, (seed, total, first) in enumerate(jobs):
@@ -121,14 +139,16 @@ def _sharded_worker(rank, world, port, out_dir, overlap, wire32, extra):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,wire32,extra", [(False, False, 0), (True, True, 0), (False, True, 0),
-                                                  (True, True, 1 << 31), (True, False, 1 << 33)])
-def test_sharded_tracer_steps_reproduce_single_process_tallies(tmp_path, overlap, wire32, extra):
+@pytest.mark.parametrize("overlap,wire32,extra,atmos32", [(False, False, 0, True), (True, True, 0, True), (False, True, 0, True),
+                                                          (True, True, 1 << 31, True), (True, False, 1 << 33, True),
+                                                          (True, True, 0, False), (False, True, 1 << 31, False)])
+def test_sharded_tracer_steps_reproduce_single_process_tallies(tmp_path, overlap, wire32, extra, atmos32):
     """ShardedTracer (the step bench.py times): three jobs over two ranks, with and without the double-buffered
     asynchronous all-reduce, with 32-bit counts on the wire -- including a count of 2^31 on one rank, which the
-    narrowing step must flag so that the exchange is repeated in 64 bits."""
+    narrowing step must flag so that the exchange is repeated in 64 bits -- and with the absorption counts native to
+    the wire (rt_bind_atmos_wire) or narrowed like the rest."""
     world = 2
-    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path), overlap, wire32, extra), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path), overlap, wire32, extra, atmos32), nprocs=world, join=True)
     sc = scenes.tiny()
     for k, (seed, total, first) in enumerate([(31, 3001, 7), (32, 2000, 100000), (33, 4099, 0)]):
         whole, _ = O.photon_oracle(sc, seed, first, total, nthreads=0)

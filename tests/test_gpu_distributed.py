@@ -178,6 +178,66 @@ def test_narrow_and_widen_kernels(tmp_path):
         tr.synchronize(); tr.close()
 
 
+def test_absorptions_counted_straight_into_the_wire(tmp_path):
+    """rt_bind_atmos_wire: two 'ranks' (two contexts on this GPU) count their absorptions as 32-bit
+    words in their wires while the five 2-D arrays stay 64-bit; narrowing then touches the 2-D words only, the summed
+    wires widened into either context's buffer equal the 64-bit sum of two ordinary runs bit for bit -- also when a 2-D
+    count raises the flag (the absorption words are widened regardless, the 2-D words left for the 64-bit repeat).
+    Refused: more photons than a 32-bit word can count, and the lane-resident kernel."""
+    import torch
+    import raytracer_amd as rt
+    scene = rt.scenes.tiny()
+    n2 = 5 * scene.ncol
+    ref = []
+    for r in range(2):
+        tr = rt.PhotonTracer.from_scene(scene, device=0)
+        tr.trace(5, r * 150_000, 150_000); tr.synchronize()
+        ref.append(_words(tr.tallies()).copy())
+        tr.close()
+    want = ref[0] + ref[1]
+    trs = [rt.PhotonTracer.from_scene(scene, device=0) for _ in range(2)]
+    n = trs[0].nwords
+    tal = [torch.full((n,), -7, dtype=torch.int64, device="cuda:0") for _ in range(2)]       # stale words must not survive
+    wire = [torch.full((n + 1,), -9, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    for r, tr in enumerate(trs):
+        tr.set_stream(torch.cuda.current_stream().cuda_stream)
+        tr.bind_tally_tensor(tal[r]); tr.bind_atmos_wire(wire[r])
+        tr.reset()
+        tr.trace(5, r * 150_000, 100_000); tr.trace_noalloc(5, r * 150_000 + 100_000, 50_000)     # accumulates across calls
+        tr.narrow_tallies(wire[r], 2, tal[r])
+    torch.cuda.synchronize()
+    for r in range(2):      # the 64-bit buffer holds the 2-D arrays only; the absorption counts are in the wire
+        assert np.array_equal(tal[r][:n2].cpu().numpy(), ref[r][:n2])
+        assert np.array_equal(wire[r][n2:-1].cpu().numpy().astype(np.int64), ref[r][n2:])
+    total = wire[0] + wire[1]
+    assert int(total[-1].item()) == 0
+    for r, tr in enumerate(trs):
+        wire[r].copy_(total)
+        tr.widen_tallies(wire[r], tal[r])
+        assert np.array_equal(tal[r].cpu().numpy(), want)
+    # a 2-D count too large for the 32-bit sum on rank 1: flagged; the widening then fills in the absorption words only
+    tr = trs[1]
+    tr.reset(); tr.trace(5, 150_000, 150_000)
+    tal[1][7] += 1 << 31
+    tr.narrow_tallies(wire[1], 2, tal[1])
+    assert int(wire[1][-1].item()) == 1
+    before2d = tal[1][:n2].cpu().numpy().copy()
+    tr.widen_tallies(wire[1], tal[1])
+    assert np.array_equal(tal[1][:n2].cpu().numpy(), before2d) and np.array_equal(tal[1][n2:].cpu().numpy(), ref[1][n2:])
+    # refusals
+    with pytest.raises(rt.RtError, match="overflow"):
+        tr.trace(5, 0, (1 << 32) - 100_000)
+    tr.set_option("pool", 0)
+    with pytest.raises(rt.RtError, match="pool kernel"):
+        tr.trace(5, 0, 10)
+    tr.set_option("pool", 128)
+    tr.bind_atmos_wire(None)        # unbound: an ordinary 64-bit run again
+    tr.reset(); tr.trace(5, 150_000, 150_000); tr.synchronize()
+    assert np.array_equal(tal[1].cpu().numpy(), ref[1])
+    for t in trs:
+        t.synchronize(); t.close()
+
+
 @pytest.mark.parametrize("wire32", [1, 0])
 def test_rt_allreduce_of_the_c_abi(wire32):
     """rt_allreduce (RCCL loaded at run time inside the library) on the one GPU there is: the sum over one context is
