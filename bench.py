@@ -49,6 +49,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 GATHER_PEAK_G = 54.7
 ATOMIC_PEAK_G = 18.2
 VALU_PEAK_GWAVEINST = 1228.8
+# ... and per footprint (the same microbenchmarks on smaller arrays): a ceiling is priced for the bytes the accesses are
+# spread over -- the packed cells for the gathers, the tally buffer for the atomics -- so that a small scene is not
+# held against the multi-GiB figure (round 2's C1 line showed frac 1.23 that way)
+GATHER_PEAK_BY_FOOTPRINT = ((16 << 20, 81.0), (128 << 20, 57.0), (2 << 30, 54.7))
+ATOMIC_PEAK_BY_FOOTPRINT = ((16 << 20, 23.8), (2 << 30, 18.2))
+
+
+def ceiling_for(footprint_bytes, table):
+    """Measured rate (G/s) for accesses spread over footprint_bytes: log-linear between the measured footprints."""
+    if footprint_bytes <= table[0][0]:
+        return table[0][1]
+    for (f0, r0), (f1, r1) in zip(table, table[1:]):
+        if footprint_bytes <= f1:
+            w = (math.log(footprint_bytes) - math.log(f0)) / (math.log(f1) - math.log(f0))
+            return r0 + w * (r1 - r0)
+    return table[-1][1]
 
 
 def parse():
@@ -129,7 +145,7 @@ def reference_binary_sample(threads, arg):
         return None
     try:
         with tempfile.TemporaryDirectory() as d:
-            r = subprocess.run([exe, str(arg)], cwd=d, env=dict(os.environ, OMP_NUM_THREADS=str(threads)),
+            r = subprocess.run([exe, str(arg)], cwd=d, env={"PATH": "/usr/bin:/bin", "OMP_NUM_THREADS": str(threads)},
                                capture_output=True, text=True, timeout=180)
             m = re.search(r"Duration:\s*([0-9.eE+-]+)", r.stdout)
             if r.returncode != 0 or not m:
@@ -175,6 +191,44 @@ def cpu_baseline(scene, seconds, workload, extra_scenes):
     if others:
         out["other_scenes"] = others
     return out
+
+
+def shared_scene(rt, factory, rank, world, share, dist):
+    """The synthetic scene of this run. With several ranks on one node only rank 0 generates it (1024 x 1024 x 128:
+    6.6 s and 5 GB of numpy temporaries) and leaves the four float32 fields in /dev/shm; the others map them read-only
+    -- eight ranks generating side by side on shared host cores would each spend that ahead of the first GPU call."""
+    if not share:
+        return getattr(rt.scenes, factory)()
+    import shutil
+    d = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"rt_bench_scene_{os.environ.get('MASTER_PORT', '0')}_{factory}")
+    names = ("k_gas", "k_cloud", "ssa", "asy")
+    if rank == 0:
+        sc = getattr(rt.scenes, factory)()
+        os.makedirs(d, exist_ok=True)
+        for name, a in zip(names, sc.fields()):
+            np.save(os.path.join(d, name + ".npy"), np.ascontiguousarray(a, dtype=np.float32))
+        with open(os.path.join(d, "meta.json"), "w") as fh:
+            json.dump({"name": sc.name, "dims": [sc.itot, sc.jtot, sc.ktot], "spacing": [sc.dx, sc.dy, sc.dz],
+                       "albedo": sc.albedo, "zenith_deg": sc.zenith_deg, "azimuth_deg": sc.azimuth_deg}, fh)
+    dist.barrier()
+    if rank != 0:
+        with open(os.path.join(d, "meta.json")) as fh:
+            m = json.load(fh)
+        fields = [np.load(os.path.join(d, name + ".npy"), mmap_mode="r") for name in names]
+        sc = rt.scenes.Scene(m["name"], *m["dims"], *m["spacing"], *fields)
+        sc.albedo, sc.zenith_deg, sc.azimuth_deg = m["albedo"], m["zenith_deg"], m["azimuth_deg"]
+    sc._shared_dir = d
+    return sc
+
+
+def release_shared_scene(scene, rank, dist):
+    d = getattr(scene, "_shared_dir", None)
+    if d is None:
+        return
+    import shutil
+    dist.barrier()              # every rank has uploaded its copy to its GPU
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def sweep_bench(args, rt, torch):
@@ -361,9 +415,10 @@ def main():
     factory, default_log2, desc = WORKLOADS[args.workload]
     log2n = args.photons_log2 if args.photons_log2 is not None else default_log2
     n_per_gpu = 1 << log2n
-    scene = getattr(rt.scenes, factory)()
+    scene = shared_scene(rt, factory, rank, world, use_dist and world > 1, dist)
 
     tr = rt.PhotonTracer.from_scene(scene, device=local_rank)
+    release_shared_scene(scene, rank, dist)
     if args.blocks_per_cu:
         tr.set_option("blocks_per_cu", args.blocks_per_cu)
     # Launch order: consecutive photon IDs sweep the columns of the domain top (the reference's launch is
@@ -535,19 +590,32 @@ def main():
                     if p.get("fabric_reads_per_photon") is not None:
                         misses = p["fabric_reads_per_photon"] * n_per_gpu
                         atomics = p.get("atomics_per_photon", 0.0) * n_per_gpu
+                        g_peak = ceiling_for(16 * scene.ncell, GATHER_PEAK_BY_FOOTPRINT)
+                        a_peak = ceiling_for(8 * tr.nwords, ATOMIC_PEAK_BY_FOOTPRINT)
                         out["gather_roofline"] = {
-                            "bound": "random 64-byte sector reads and 64-bit atomics (measured ceilings, G/s)",
+                            "bound": "random 64-byte sector reads and 64-bit atomics (ceilings measured for this footprint, G/s)",
                             "sector_reads_per_photon": p["fabric_reads_per_photon"],
                             "atomics_per_photon": p.get("atomics_per_photon"),
-                            "peak_sector_reads_G_per_s": GATHER_PEAK_G, "peak_atomics_G_per_s": ATOMIC_PEAK_G,
-                            "frac": (misses / GATHER_PEAK_G + atomics / ATOMIC_PEAK_G) * 1e-9 / kt}
+                            "peak_sector_reads_G_per_s": g_peak, "peak_atomics_G_per_s": a_peak,
+                            "footprint_bytes": {"cells": 16 * scene.ncell, "tallies": 8 * tr.nwords},
+                            "frac": (misses / g_peak + atomics / a_peak) * 1e-9 / kt}
                     if p.get("valu_wave_insts_per_photon") is not None:
+                        valu_achieved = p["valu_wave_insts_per_photon"] * n_per_gpu / kt / 1e9
                         out["valu_roofline"] = {
                             "wave_insts_per_photon": p["valu_wave_insts_per_photon"],
                             "active_lanes": p.get("active_lanes_per_valu_inst"),
                             "peak_G_wave_insts_per_s": VALU_PEAK_GWAVEINST,
                             "sustained_by_microbenchmark_G_wave_insts_per_s": 1040.0,   # v_xor_b32, 8 waves/SIMD
-                            "frac": p["valu_wave_insts_per_photon"] * n_per_gpu / kt / 1e9 / VALU_PEAK_GWAVEINST}
+                            "frac": valu_achieved / VALU_PEAK_GWAVEINST}
+                        # roofline.achieved = max(bytes / BW_peak, valu / VALU_peak), `bound` names
+                        # the binding ceiling. The streaming-HBM figure (measured live) stays in roofline.hbm; the VALU
+                        # instruction count per photon is the replayed counter, the kernel time is this run's.
+                        hbm = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac")}
+                        out["roofline"]["hbm"] = hbm
+                        if valu_achieved / VALU_PEAK_GWAVEINST > hbm["frac"]:
+                            out["roofline"].update({"bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK_GWAVEINST,
+                                                    "unit": "G wave-instructions/s (wave64 VALU, 2-cycle issue x 1024 SIMDs x 2.4 GHz)",
+                                                    "frac": valu_achieved / VALU_PEAK_GWAVEINST})
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -393,7 +393,11 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     for (int g = 0; g < c.ngpus; ++g)
     {
         check(rt_create(g, c.itot, c.jtot, c.ktot, c.dx, c.dy, c.dz, &ctx[g]), "rt_create");
-        check(rt_upload_optics(ctx[g], k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
+    }
+    // the four fields to every GPU side by side (page-locked for the call, asynchronous copies)
+    check(rt_upload_optics_multi(ctx.data(), c.ngpus, k_gas.data(), k_cloud.data(), ssa.data(), asy.data()), "rt_upload_optics");
+    for (int g = 0; g < c.ngpus; ++g)
+    {
         check(rt_set_option(ctx[g], "fixed_dot", c.fixed_dot), "rt_set_option");
         check(rt_set_option(ctx[g], "launch_log2k", launch_log2k), "rt_set_option");
         check(rt_set_option(ctx[g], "launch_tile_log2", launch_tile_log2), "rt_set_option");

@@ -105,6 +105,13 @@ int rt_destroy(rt_context* ctx);
 int rt_upload_optics(rt_context* ctx, const float* k_ext_gas, const float* k_ext_cloud,
                      const float* ssa, const float* asy);
 
+/* The same fields to n contexts (one per GPU, same grid) at once: the host arrays are page-locked for the call and
+ * the copies to all GPUs are enqueued before any is waited for, so the GPUs' links to the host work side by side
+ * (the multi-GPU drivers; rt_upload_optics per GPU in turn moves 2 GiB of pageable memory eight times over, one after
+ * another, on the 1024 x 1024 x 128 grid). The reference has one GPU. */
+int rt_upload_optics_multi(rt_context* const ctx[], int n, const float* k_ext_gas, const float* k_ext_cloud,
+                           const float* ssa, const float* asy);
+
 /* Same, from device pointers already resident on the context's GPU (no PCIe in the path). */
 int rt_upload_optics_device(rt_context* ctx, const float* d_k_ext_gas, const float* d_k_ext_cloud,
                             const float* d_ssa, const float* d_asy);

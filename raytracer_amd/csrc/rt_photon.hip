@@ -2993,6 +2993,45 @@ int rt_upload_optics(rt_context* c, const float* k_gas, const float* k_cloud, co
     return rc;
 }
 
+int rt_upload_optics_multi(rt_context* const ctx[], int n, const float* k_gas, const float* k_cloud, const float* ssa, const float* asy)
+{
+    if (!ctx || n < 1 || !k_gas || !k_cloud || !ssa || !asy) return fail(RT_ERR_ARG, "rt_upload_optics_multi: bad argument");
+    for (int g = 0; g < n; ++g)
+        if (!ctx[g] || ctx[g]->ncell != ctx[0]->ncell) return fail(RT_ERR_ARG, "rt_upload_optics_multi: context %d is null or has another grid", g);
+    const size_t ncell = ctx[0]->ncell, bytes = sizeof(float) * ncell;
+    const float* const src[4] = {k_gas, k_cloud, asy, ssa};       // staging order of the pack kernel: gas | cloud | asy | ssa
+    // page-lock the caller's arrays for the duration of the call, so that the copies to all GPUs are true asynchronous
+    // DMA and run side by side (each GPU has its own link to the host); arrays that cannot be locked are copied pageable
+    bool locked[4] = {false, false, false, false};
+    for (int f = 0; f < 4; ++f)
+        locked[f] = hipHostRegister(const_cast<float*>(src[f]), bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    std::vector<float*> tmp(n, nullptr);
+    int rc = RT_OK;
+    for (int g = 0; g < n && rc == RT_OK; ++g)
+    {
+        rt_context* c = ctx[g];
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipMalloc(&tmp[g], 4 * bytes);
+        for (int f = 0; f < 4 && e == hipSuccess; ++f)
+            e = hipMemcpyAsync(tmp[g] + (size_t)f * ncell, src[f], bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_upload_optics_multi: GPU %d: %s", c->device, hipGetErrorString(e));
+    }
+    for (int g = 0; g < n; ++g)
+    {
+        rt_context* c = ctx[g];
+        (void)hipSetDevice(c->device);
+        if (rc == RT_OK && tmp[g])
+            rc = pack_from_device(c, tmp[g], tmp[g] + ncell, tmp[g] + 3 * ncell, tmp[g] + 2 * ncell);
+        else
+            (void)hipStreamSynchronize(c->stream);
+        if (tmp[g]) (void)hipFree(tmp[g]);
+    }
+    for (int f = 0; f < 4; ++f)
+        if (locked[f]) (void)hipHostUnregister(const_cast<float*>(src[f]));
+    return rc;
+}
+
 int rt_upload_optics_device(rt_context* c, const float* d_gas, const float* d_cloud, const float* d_ssa, const float* d_asy)
 {
     if (!c || !d_gas || !d_cloud || !d_ssa || !d_asy) return fail(RT_ERR_ARG, "rt_upload_optics_device: null pointer");

@@ -70,6 +70,7 @@ def load_library():
         "rt_destroy": (C.c_int, [vp]),
         "rt_upload_optics": (C.c_int, [vp] + [f32p] * 4),
         "rt_upload_optics_device": (C.c_int, [vp] * 5),
+        "rt_upload_optics_multi": (C.c_int, [C.POINTER(vp), C.c_int] + [f32p] * 4),
         "rt_set_scene": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),
         "rt_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
         "rt_set_stream": (C.c_int, [vp, vp]),

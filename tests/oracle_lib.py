@@ -13,7 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# RT_ORACLE_LIB: another build of the checker (tools/ubsan.sh: the UBSan build of oracle/Makefile's `ubsan` target)
+LIB_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 REF_BIN = os.path.join(ORACLE_DIR, "_ref", "raytracer_3d_ref")
 
 TALLY_NAMES = ("toa_down", "toa_up", "surface_down_direct", "surface_down_diffuse", "surface_up",
@@ -223,7 +224,7 @@ def scene_to_f64(scene):
 
 def run_reference_binary(arg: int, workdir: str, nthreads: int = 1):
     """Run the compiled reference (oracle/_ref/raytracer_3d_ref <arg>) in workdir; returns tallies."""
-    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    env = {"PATH": "/usr/bin:/bin", "OMP_NUM_THREADS": str(nthreads)}    # (compiled from public source: a minimal environment)
     subprocess.run([REF_BIN, str(arg)], cwd=workdir, check=True, env=env, stdout=subprocess.DEVNULL)
     out = {}
     for n in TALLY_NAMES:
@@ -284,7 +285,7 @@ def cpu_ref_2d(s, n_photons, nthreads=1, serial_seed=False):
 
 def run_reference_binary_2d(arg: int, workdir: str, nthreads: int = 1):
     """Run the compiled reference (oracle/_ref/raytracer_2d_ref <arg>) in workdir; returns its six tallies."""
-    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    env = {"PATH": "/usr/bin:/bin", "OMP_NUM_THREADS": str(nthreads)}
     subprocess.run([REF2D_BIN, str(arg)], cwd=workdir, check=True, env=env, stdout=subprocess.DEVNULL)
     return {n: np.fromfile(os.path.join(workdir, n + ".bin"), dtype=np.uint64).reshape((128, 256) if n == "atmos" else (256,))
             for n in TALLY_NAMES_2D}

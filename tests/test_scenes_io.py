@@ -130,22 +130,48 @@ def test_converter_follows_make_binary(tmp_path):
         convert.load_fields(str(tmp_path / "missing.nc"))
 
 
+def _plot_script_reads(directory, itot=128, jtot=128, ktot=128):
+    """What the reference's plot script does with a run's output before it plots (plot_results_3d.py:8-10, 28-48),
+    restated: seven headerless uint64 files by name, the five 2-D ones reshaped (jtot, itot), the two 3-D ones
+    (ktot, jtot, itot); photon balance in - out with out = surface_down - surface_up + toa_up + atmos."""
+    def rd(name, shape):
+        return np.fromfile(os.path.join(directory, name + ".bin"), dtype=np.uint64).reshape(shape)
+    surface_down = rd("surface_down_direct", (jtot, itot)) + rd("surface_down_diffuse", (jtot, itot))
+    surface_up, toa_up, toa_down = rd("surface_up", (jtot, itot)), rd("toa_up", (jtot, itot)), rd("toa_down", (jtot, itot))
+    atmos = rd("atmos_direct", (ktot, jtot, itot)) + rd("atmos_diffuse", (ktot, jtot, itot))
+    balance_in = np.int64(toa_down.sum())
+    balance_out = np.int64(surface_down.sum() - surface_up.sum() + toa_up.sum() + atmos.sum())
+    return int(balance_in), int(balance_out), int(balance_in - balance_out), float(toa_down.mean())
+
+
+def test_t7_outputs_read_the_way_the_plot_script_reads_them(tmp_path):
+    """SURVEY.md section 4, T7, wherever the tests run: files written by save_tallies for the reference's 128^3 scene,
+    read by name, dtype and shape as plot_results_3d.py:28-35 reads them, give its photon balance of 0 (:41-48) and
+    the normalisation it divides by (:52)."""
+    sc = scenes.block_cloud()
+    t, _ = O.photon_oracle(sc, 2, 0, 400_000)
+    save_tallies(t, str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == sorted(n + ".bin" for n in O.TALLY_NAMES)
+    b_in, b_out, net, norm = _plot_script_reads(str(tmp_path))
+    assert (b_in, b_out, net) == (400_000, 400_000, 0) and norm == 400_000 / (128 * 128)
+
+
 REF_PLOT = "/root/reference/python/plot_results_3d.py"
 
 
 @pytest.mark.skipif(not os.path.exists(REF_PLOT), reason="the reference tree is only present in the build container")
 def test_t7_reference_plot_script_runs_unmodified_on_our_files(tmp_path):
-    """the reference's own plot_results_3d.py, run as it is (headless, MPLBACKEND=Agg) in a
-    directory written by save_tallies for its 128^3 scene, reads the seven files and prints a photon balance of 0
-    (plot_results_3d.py:28-48). The tallies come from the CPU oracle here (the GPU drivers write the same files:
-    tests/test_gpu_drivers.py)."""
+    """The same with the reference's own plot_results_3d.py run as it is (headless) in that directory -- where the
+    reference tree exists; elsewhere parity with the script itself rests on the restatement above. The script is public,
+    untrusted code: it gets an environment of four variables, not the test process's."""
     import subprocess
     import sys
     sc = scenes.block_cloud()
     t, _ = O.photon_oracle(sc, 2, 0, 400_000)
     save_tallies(t, str(tmp_path))
-    env = dict(os.environ, MPLBACKEND="Agg", MPLCONFIGDIR=str(tmp_path))
+    env = {"PATH": "/usr/bin:/bin", "HOME": str(tmp_path), "MPLBACKEND": "Agg", "MPLCONFIGDIR": str(tmp_path)}
     r = subprocess.run([sys.executable, REF_PLOT], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = dict(l.split(":", 1) for l in r.stdout.splitlines() if ":" in l)
     assert int(lines["in"]) == 400_000 and int(lines["out"]) == 400_000 and int(lines["balance"]) == 0
+    assert (int(lines["in"]), int(lines["out"]), int(lines["balance"])) == _plot_script_reads(str(tmp_path))[:3]
