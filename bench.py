@@ -70,7 +70,7 @@ def ceiling_for(footprint_bytes, table):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --workload c5: 6 = one sweep of the zenith angles)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--photons-log2", type=int, default=None, help="photons per GPU per step (log2)")
@@ -325,7 +325,7 @@ def sweep_bench(args, rt, torch):
                 "kernel_ms": sum(kernel_ms) / len(kernel_ms), "file_write_s_per_job": write_s / steps,
                 "file_write_GB_per_s": wrote / max(write_s, 1e-9) / 1e9, "events": ev}
 
-    steps = args.steps if args.steps != 3 else len(C5_ZENITHS)          # default: one sweep of the six angles
+    steps = args.steps if args.steps is not None else len(C5_ZENITHS)   # default: one sweep of the six angles
     warmup = max(args.warmup, 1)
     with tempfile.TemporaryDirectory(dir=args.outdir) as d:
         io_scene = rt.scenes.cumulus(240, 240, 284, 100.0, 100.0, 30.0, n_clouds=60, seed=7, z_base=900.0, z_top=3000.0,
@@ -384,6 +384,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    if args.workload != "c5" and args.steps is None:
+        args.steps = 3
     if args.workload == "c5":
         if world != 1:
             raise SystemExit("--workload c5 is a one-GPU measurement (its runs are independent jobs)")

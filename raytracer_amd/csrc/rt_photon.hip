@@ -2671,8 +2671,7 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         memset(&so, 0, sizeof(so));
         if (sorted)
         {
-            so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;   // (or once allocated, below)
-            so.seed = seed;
+            so.seed = seed;             // (list and tables: per batch, once the list exists)
             so.tile_shift = (uint32_t)c->sort_tile_log2;
             const auto tiles_along = [&](int n) { return (uint32_t)((n + (1 << so.tile_shift) - 1) >> so.tile_shift); };
             while ((uint64_t)tiles_along(c->itot) * tiles_along(c->jtot) > kSortMaxTiles) ++so.tile_shift;
@@ -2723,8 +2722,11 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
                     c->d_sort = nullptr; c->sort_capacity = 0;
                     RT_HIP(hipMalloc(&c->d_sort, sizeof(uint32_t) * (need + kSortMaxTiles * (1 + sort_blocks(c)))));
                     c->sort_capacity = need;
-                    so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;
                 }
+            }
+            if (sorted_now)
+            {
+                so.list = c->d_sort; so.tile_base = c->d_sort + c->sort_capacity; so.count = so.tile_base + kSortMaxTiles;
             }
             // IDs go out in chunks from a device-wide cursor; small jobs get smaller chunks so that
             // every resident wave still finds work
