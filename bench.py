@@ -618,6 +618,15 @@ def main():
                             out["roofline"].update({"bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK_GWAVEINST,
                                                     "unit": "G wave-instructions/s (wave64 VALU, 2-cycle issue x 1024 SIMDs x 2.4 GHz)",
                                                     "frac": valu_achieved / VALU_PEAK_GWAVEINST})
+                        # ... and (i) of that section for grids inside the caches: the random-access ceiling measured by
+                        # the microbenchmarks over the same footprint (64-byte sector reads + 64-bit atomics, additive)
+                        g = out.get("gather_roofline")
+                        if g and g["frac"] > out["roofline"]["frac"]:
+                            acc = (g["sector_reads_per_photon"] + (g["atomics_per_photon"] or 0.0)) * n_per_gpu / kt / 1e9
+                            out["roofline"].update({"bound": "gather", "achieved": acc, "peak": acc / g["frac"],
+                                                    "unit": "G random accesses/s (64-byte sector reads + 64-bit atomics at the "
+                                                            "rates measured for this footprint, additive)",
+                                                    "frac": g["frac"]})
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

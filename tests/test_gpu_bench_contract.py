@@ -30,7 +30,7 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     roof = d["roofline"]
     # bound names the binding ceiling: "valu" only when the committed counters of exactly this
     # workload and photon count are replayed; the streaming-HBM figure is then kept in roofline.hbm
-    assert roof["bound"] in ("hbm", "valu") and roof["kernel_ms"] > 0 and 0 < roof["frac"] <= 1.0
+    assert roof["bound"] in ("hbm", "valu", "gather") and roof["kernel_ms"] > 0 and 0 < roof["frac"] <= 1.0
     hbm = roof if roof["bound"] == "hbm" else roof["hbm"]
     assert hbm["unit"] == "GB/s" and hbm["peak"] == 8000.0 and abs(hbm["frac"] - hbm["achieved"] / hbm["peak"]) < 1e-12
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
