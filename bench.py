@@ -493,6 +493,8 @@ def main():
     if balance != 0 or launched != n_per_gpu * world:
         raise SystemExit(f"bench: invalid result (balance {balance}, launched {launched}, expected {n_per_gpu * world})")
 
+    if sharded.atmos32:
+        tr.bind_atmos_wire(None)        # what follows reads this context's own 64-bit tallies again
     out = None
     if rank == 0:
         # event counters of exactly one launch (same photon range as the last timed step of rank 0)
