@@ -143,3 +143,22 @@ def test_c3_cumulus_2p28_photons_sobol_launch_against_reference_restatement(rt):
     assert int(np.abs(a["toa_down"].astype(np.int64) - per_col).max()) <= 4       # 2^16 columns: a (0,2)-net per 2^16 IDs
     _, rep = _check_against_fixture(a, n, "cpu_ref_c3_1e8.npz", scene, {"blocks": TWO_D[1:], "sub_poisson": ("surface_down_direct",)})
     assert rep["z2_surface_down_direct"] < 0.95      # the direct beam at the surface is visibly less noisy than Poisson
+
+
+def test_c4_les_grid_2p30_photons_sobol_launch_against_reference_restatement(rt):
+    """north_star's target with the reference's own launch: 2^30 photons through the 1024x1024x128 LES grid as four
+    accumulating calls of 2^28 (the shards of four ranks), Sobol launch in box order. Exact balance; toa_down EXACTLY 1024 per
+    column (2^20 columns: every aligned 2^20 IDs are a net with one point per column; positions live on the 2^-24 lattice,
+    on which a column is a whole number of steps); against 6*10^7 photons of oracle/cpu_ref.cpp (fixture
+    cpu_ref_c4_6e7.npz): global fractions within 4 sigma, z-scores of the 16x16-column-block sums and per-level absorption."""
+    scene = rt.scenes.cumulus_c4()
+    n = 1 << 30
+    tr = rt.PhotonTracer.from_scene(scene, launch_log2k=SOBOL)
+    for r in range(4):
+        tr.trace(23, r * (n // 4), n // 4)
+    tr.synchronize()
+    a = tr.tallies()
+    tr.close()
+    assert rt.photon_balance(a) == 0 and int(a["toa_down"].sum()) == n
+    assert int(np.abs(a["toa_down"].astype(np.int64) - n // scene.ncol).max()) <= 8
+    _check_against_fixture(a, n, "cpu_ref_c4_6e7.npz", scene, {"blocks": TWO_D[1:], "sub_poisson": ("surface_down_direct",)})
