@@ -167,6 +167,10 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    grids larger than the caches (the reference has no counterpart: its launch order is the
  *                    thread index, raytracer_kernels.cu:323-331)
  *   "th_launch"      free slots of a wave's pool that trigger a launch (regeneration) round
+ *   "tally_match"    pool kernel: rounds in which a wave first adds the 2-D tally words that many of its lanes
+ *                    share (the direct beam of one launch column) with one atomic each, before the runs of equal
+ *                    neighbouring lanes; 0..16, -1 (default) = 6 on grids of up to 2^15 columns, 0 on larger ones
+ *                    (scheduling only; the reference adds one by one, raytracer_kernels.cu:256-261)
  *   "chunk"          photon IDs a wave of the pool kernel takes at a time from the device-wide cursor
  *                    (power of two, default 256; halved for small jobs until every wave finds work)
  *   "pool"           photons each wave keeps in LDS (64, 96, 128, 160, 192 or 256) and compacts by

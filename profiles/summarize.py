@@ -15,10 +15,11 @@ tag, workload, photons = sys.argv[1], sys.argv[2], int(sys.argv[3])
 launch_log2k = int(sys.argv[4]) if len(sys.argv) > 4 else -1     # bench.py --launch-log2k of the profiled run
 src = f"gpurun_out/prof_{tag}"
 here = os.path.dirname(os.path.abspath(__file__))
-shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"{here}/{tag}_kernel_stats.csv")
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)     # gpurun_out/ keeps earlier runs' files beside the last one's
+shutil.copy(newest(f"{src}/trace/*/*_kernel_stats.csv"), f"{here}/{tag}_kernel_stats.csv")
 pmc = {}
 for d in sorted(glob.glob(f"{src}/pmc_*/")):
-    for f in glob.glob(d + "*/*_counter_collection.csv"):
+    for f in [newest(d + "*/*_counter_collection.csv")]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]

@@ -199,6 +199,23 @@ def test_pool_kernel_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid)
     tr.close()
 
 
+@pytest.mark.parametrize("stats", [0, 1])
+@pytest.mark.parametrize("scene_name,n", [("block_cloud", 1 << 18), ("cloud_to_ground", 1 << 16), ("tiny", 70_001)])
+def test_matching_of_tally_words_across_the_wave_does_not_change_results(rt, stats, scene_name, n):
+    """Option tally_match (the rounds in which the pool kernel adds 2-D tally words shared by many lanes with one
+    atomic each, before the runs of equal neighbours): off, one round, automatic, the maximum -- in the kernel with the
+    event counters and in the tuned one, which exists with and without the matching code."""
+    scene = SCENES[scene_name](rt.scenes)
+    want, ev = O.photon_oracle(scene, 55, 1 << 33, n)
+    for rounds in (0, 1, -1, 16):
+        tr = rt.PhotonTracer.from_scene(scene, stats=stats, tally_match=rounds)
+        tr.trace(55, 1 << 33, n); tr.synchronize()
+        _assert_same(tr.tallies(), want)
+        if stats:
+            assert tr.events() == ev
+        tr.close()
+
+
 @pytest.mark.parametrize("chunk,n", [(64, 1 << 16), (512, 1 << 16), (4096, 1 << 17), (1 << 16, 100_003), (512, 777)])
 def test_chunked_id_distribution_does_not_change_results(rt, chunk, n):
     """The pool kernel hands photon IDs to its waves in chunks from a device-wide cursor: which wave
@@ -476,7 +493,7 @@ def test_errors_are_reported_not_fatal(rt):
         tr.set_option("no_such_option", 1)
     with pytest.raises(rt.RtError):
         tr.set_scene(zenith_deg=95.0)
-    for name, bad in (("levels", 8), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
+    for name, bad in (("levels", 8), ("tally_match", 17), ("tally_match", -2), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
                       ("pool", 100), ("launch_log2k", 21), ("th_launch", 0), ("supergrid_x", -2), ("pool_waves_per_cu", 0)):
         with pytest.raises(rt.RtError, match=name):
             tr.set_option(name, bad)
