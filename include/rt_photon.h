@@ -131,12 +131,13 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: the whole number of
  *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or sorted
  *                    or the grid fits the Infinity Cache, else 8, 8, 4 unmerged)
- *   "levels"         supervoxels are merged bottom-up into aligned boxes of up to 2^levels supervoxels per edge -- each
- *                    axis on its own: cubes where the field is homogeneous all around, tall columns of clear air
- *                    between clouds, flat layers under them -- each crossed as one majorant region, wherever
- *                    (majorant - mean extinction) * 6 V / S of the box <= "merge_tau_milli" / 1000 -- the optical
- *                    depth of null collisions a crossing photon would meet (levels = 0: one region per supervoxel;
- *                    defaults -1 = automatic, 5 or 0 as for the supervoxel size, and 1000)
+ *   "levels"         every supervoxel gets a box of its own -- the supervoxels around it, up to 2^levels per axis, that
+ *                    a photon standing in it crosses as one majorant region (cubes where the field is homogeneous all
+ *                    around, tall columns of clear air between clouds, flat layers under them; boxes of neighbours
+ *                    overlap) -- grown a layer at a time for as long as (majorant - mean extinction) * 6 V / S of the
+ *                    box <= "merge_tau_milli" / 1000 -- the optical depth of null collisions a crossing photon would
+ *                    meet (levels = 0: one region per supervoxel; 0..5; defaults -1 = automatic, 5 or 0 as for the
+ *                    supervoxel size, and 1000)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change; they steer the
@@ -305,14 +306,18 @@ int rt_bind_atmos_wire(rt_context* ctx, void* wire, size_t n_words);
 /* Slabs, majorants and cloud bounds derived by rt_upload_optics + rt_set_scene. */
 int rt_get_slabs(rt_context* ctx, rt_slab_info* out);
 
-/* The majorant grid of the cloud slab as nck*ncj*nci pairs {M, 1/M}, [ck][cj][ci] (n_pairs must
- * equal nck*ncj*nci of rt_get_slabs). Test/diagnostic access; no counterpart in the reference. */
+/* The majorant grid of the cloud slab as nck*ncj*nci pairs {M, 1/M}, [ck][cj][ci] (n_pairs must equal nck*ncj*nci of
+ * rt_get_slabs): M of the supervoxel's box (rt_get_region_boxes) and the reciprocal the traverse steps take from it.
+ * Test/diagnostic access; no counterpart in the reference. */
 int rt_get_majorants(rt_context* ctx, float* out_pairs, size_t n_pairs);
 
-/* The region levels of every supervoxel, [ck][cj][ci] (n must equal nck*ncj*nci), lx | ly << 3 | lz << 6: its majorant
- * region is the aligned box of 2^lx x 2^ly x 2^lz supervoxels around it (clipped at the grid); rt_get_majorants
- * returns the region's pair. Test/diagnostic access; no counterpart in the reference. */
-int rt_get_region_levels(rt_context* ctx, uint16_t* out, size_t n);
+/* The majorant box of every supervoxel, [ck][cj][ci] (n must equal nck*ncj*nci): six extents of 5 bits,
+ * xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25 -- a photon in supervoxel (ci, cj, ck) crosses the supervoxels
+ * [ci - xm, ci + xp] x [cj - ym, cj + yp] x [ck - zm, ck + zp] as ONE region under the majorant rt_get_majorants returns for
+ * it (boxes of neighbours overlap; option "levels": at most 2^levels supervoxels per axis, "merge_tau_milli": how much
+ * null-collision optical depth a box may cost). Generalises the reference's three slabs with one majorant each
+ * (raytracer_kernels.cu:360-362). Test/diagnostic access. */
+int rt_get_region_boxes(rt_context* ctx, uint32_t* out, size_t n);
 
 /* Event counters accumulated since the last rt_reset_tallies (needs option "stats" = 1 for all
  * but RT_EV_ABORT). Synchronises first. */

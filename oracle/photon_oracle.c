@@ -240,11 +240,11 @@ typedef struct
                    a scattering turns the direction by +-acos(mu) in that plane (raytracer.cpp:360-364), the
                    surface reflects to (+-mu, 0, sqrt(1-mu^2)) (raytracer.cpp:280-282); the signs are the top
                    bit of the draw that is the azimuth in 3D. Meant for jtot = 1 and azimuth = 0. */
-    int levels; /* supervoxels are merged bottom-up into aligned boxes of up to 2^levels supervoxels per edge (each
-                   axis on its own), each crossed as ONE majorant region, wherever that wastes little (0 = no merging) */
-    float merge_tau; /* two buddy regions are merged when (majorant - mean extinction) * 6 V / S <= merge_tau: the
-                        optical depth of null collisions a photon crossing the box would meet. Clear air merges
-                        at any size, homogeneous cloud too; cloud edges keep their fine supervoxels. */
+    int levels; /* every supervoxel gets a box of its own, up to 2^levels supervoxels per axis, that a photon standing in
+                   it crosses as ONE majorant region (0 = the supervoxel alone) */
+    float merge_tau; /* a box grows by a layer while (majorant - mean extinction) * 6 V / S <= merge_tau: the optical
+                        depth of null collisions a photon crossing the box would meet. Clear air grows at any size,
+                        homogeneous cloud too; cloud edges keep their fine supervoxels. */
     int launch_tile_log2; /* stratified launch: 0 = columns in row-major order; T > 0 = columns counted tile by tile
                              (tiles of 2^T x 2^T columns, row-major inside, tiles row by row; itot and jtot are
                              multiples of 2^T) */
@@ -265,13 +265,13 @@ typedef struct
     int gslab;          /* index of the gridded slab, -1 if none */
     int nci, ncj, nck;  /* supervoxels per axis */
     float hx, hy, hz;   /* supervoxel edge lengths */
-    float* maj;         /* nck*ncj*nci pairs {M, 1/M} of the REGION a supervoxel belongs to; owned,
-                           freed by oracle_free_slabs */
-    uint16_t* lvl;      /* nck*ncj*nci region levels lx | ly << 3 | lz << 6: the supervoxel's region is the aligned box of
-                           2^lx x 2^ly x 2^lz supervoxels that contains it (clipped at the grid) */
+    float* maj;         /* nck*ncj*nci pairs {M, 1/M} of the BOX of a supervoxel; owned, freed by oracle_free_slabs */
+    uint32_t* box;      /* nck*ncj*nci boxes: six extents of 5 bits, xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25:
+                           a photon in supervoxel (ci, cj, ck) crosses the supervoxels [ci - xm, ci + xp] x [cj - ym, cj + yp] x
+                           [ck - zm, ck + zp] as one region */
 } oracle_slabs_t;
 
-void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->lvl); s->lvl = NULL; }
+void oracle_free_slabs(oracle_slabs_t* s) { free(s->maj); s->maj = NULL; free(s->box); s->box = NULL; }
 
 /* 1/M as the tables hold it: finite. A region without any extinction has M = 0 (or, once the region level
  * is packed into M's low mantissa bits, a denormal) and 1/M = +inf; the traverse step computes tau * (1/M), which
@@ -283,91 +283,83 @@ static inline float majorant_reciprocal(float m)
     return fminf(1.0f / m, FLT_MAX);
 }
 
-/* Majorant regions over the supervoxel grid: aligned BOXES of 2^lx x 2^ly x 2^lz supervoxels (clipped at the grid),
- * grown bottom-up by merging buddies. Sweep s = 0, 1, 2, ... works on axis s mod 3 (x, y, z in turn) at level
- * t = s / 3: a region whose level along that axis is t and whose origin has bit t of that coordinate clear merges
- * with its buddy -- the region of the same shape that starts 2^t supervoxels further along the axis -- if
- * (M - mean k_tot) * len <= tau, with M the maximum and mean the volume mean of the extinction over both, and
- * len = 6 V / S of the merged box (its edge if it is a cube; three times its thickness if it is a wide slab): the
- * optical depth of null collisions a crossing photon meets on average, up to the factor 2/3 of the mean chord.
- * A buddy that lies outside the grid merges trivially (the clipped region only moves up a level, so that it can
- * still meet its buddies along the other axes). Growing the three axes in turn gives cubes where the field is
- * homogeneous around them -- clear air and the inside of a cloud -- and boxes that go on along one or two axes
- * where the others are blocked: tall columns of clear air between clouds, flat layers under and over them.
- * maj: pairs {M, 1/M} per supervoxel in, per region out. ksum/kcnt: sum (double, cells in k, j, i order) and number
- * of cells per supervoxel. The criterion is evaluated in double, sums are added lower region first, regions are
- * visited in index order: the library's copy of this routine must decide identically.
- * lvl[e] = lx | ly << 3 | lz << 6 of the region supervoxel e belongs to. */
-static void build_regions(int nci, int ncj, int nck, int max_level, float* maj, const double* ksum, const int* kcnt,
-                          float hx, float hy, float hz, float tau, uint16_t* lvl)
+/* 1/M of a box as the traverse steps take it from M (the product's region_reciprocal): the IEEE quotient for
+ * M >= 2^-100, FLT_MAX below. */
+static inline float region_reciprocal(float m)
 {
-    const size_t n = (size_t)nci * ncj * nck;
+    return m >= 0x1p-100f ? 1.0f / m : FLT_MAX;
+}
+
+/* Majorant regions over the supervoxel grid: every supervoxel gets a BOX OF ITS OWN -- the supervoxels around it, at
+ * most max_extent per axis, clipped at the grid -- that a photon standing in it crosses as one region under the box's
+ * majorant. Boxes of neighbours overlap: they are no partition, and need not be -- every step of the walk is made
+ * under a majorant that bounds the extinction over the whole segment, and the optical depth carried over a face is
+ * decremented with the majorant the segment was sampled with.
+ * Growth: from the supervoxel alone, one layer at a time, trying the six faces in turn (x-, x+, y-, y+, z-, z+) until
+ * six attempts in a row have failed; a layer is taken if (M - mean k_tot) * len <= tau for the grown box, M its
+ * majorant, mean its volume mean, len = 6 V / S (the edge of a cube; three times the thickness of a wide slab): the
+ * optical depth of null collisions a crossing photon meets on average, up to the factor 2/3 of the mean chord.
+ * m0: majorant per supervoxel; ksum/kcnt: sum (double, cells in k, j, i order) and number of its cells. The layer's
+ * supervoxels are visited in (k, j, i) order and the criterion is evaluated in double: the library's kernel
+ * (rt_boxes_kernel) must decide identically. */
+static void build_boxes(int nci, int ncj, int nck, int max_extent, const float* m0, const double* ksum, const int* kcnt,
+                        float hx, float hy, float hz, float tau, float* maj, uint32_t* box)
+{
+    const long long n = (long long)nci * ncj * nck;
     const int dims[3] = {nci, ncj, nck};
     const double h[3] = {(double)hx, (double)hy, (double)hz};
-    memset(lvl, 0, n * sizeof(uint16_t));
-    float* rmax = (float*)malloc(sizeof(float) * n);        /* per region, kept at its origin supervoxel */
-    double* rsum = (double*)malloc(sizeof(double) * n);
-    long long* rcnt = (long long*)malloc(sizeof(long long) * n);
-    for (size_t e = 0; e < n; ++e) { rmax[e] = maj[2 * e]; rsum[e] = ksum[e]; rcnt[e] = kcnt[e]; }
-    for (int sweep = 0; sweep < 3 * max_level; ++sweep)
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long long e = 0; e < n; ++e)
     {
-        const int axis = sweep % 3, t = sweep / 3;
-        for (int k = 0; k < nck; ++k)
-            for (int j = 0; j < ncj; ++j)
-                for (int i = 0; i < nci; ++i)
-                {
-                    const size_t e = ((size_t)k * ncj + j) * nci + i;
-                    const int l[3] = {lvl[e] & 7, (lvl[e] >> 3) & 7, (lvl[e] >> 6) & 7};
-                    const int o[3] = {i, j, k};
-                    /* origins of regions at level t along the axis, lower buddy only */
-                    if (l[axis] != t || (i & ((1 << l[0]) - 1)) || (j & ((1 << l[1]) - 1)) || (k & ((1 << l[2]) - 1))) continue;
-                    if ((o[axis] >> t) & 1) continue;
-                    int bo[3] = {i, j, k};
-                    bo[axis] += 1 << t;
-                    int hi[3];          /* clipped end of the merged box */
-                    for (int d = 0; d < 3; ++d)
-                    {
-                        const int len = 1 << (l[d] + (d == axis ? 1 : 0));
-                        hi[d] = o[d] + len < dims[d] ? o[d] + len : dims[d];
-                    }
-                    if (bo[axis] < dims[axis])
-                    {
-                        const size_t be = ((size_t)bo[2] * ncj + bo[1]) * nci + bo[0];
-                        if (lvl[be] != lvl[e]) continue;            /* the buddy is not a region of the same shape */
-                        const float m = rmax[be] > rmax[e] ? rmax[be] : rmax[e];
-                        const double sum = rsum[e] + rsum[be];
-                        const long long cnt = rcnt[e] + rcnt[be];
-                        const double ex = (double)(hi[0] - o[0]) * h[0], ey = (double)(hi[1] - o[1]) * h[1],
-                                     ez = (double)(hi[2] - o[2]) * h[2];
-                        const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
-                        if (((double)m - sum / (double)cnt) * len > (double)tau) continue;
-                        rmax[e] = m; rsum[e] = sum; rcnt[e] = cnt;
-                    }
-                    const uint16_t nl = (uint16_t)(lvl[e] + (1u << (3 * axis)));
-                    for (int kk = k; kk < hi[2]; ++kk)
-                        for (int jj = j; jj < hi[1]; ++jj)
-                            for (int ii = i; ii < hi[0]; ++ii)
-                                lvl[((size_t)kk * ncj + jj) * nci + ii] = nl;
-                }
-    }
-    /* every supervoxel takes its region's majorant (kept at the region's origin). The levels ride in the nine low
-     * mantissa bits of M, rounded UP to make room (still a majorant, larger by < 2^-14 of itself), and 1/M is taken
-     * from the packed value: one 8-byte table entry tells a traverse step everything about its region. */
-    for (int k = 0; k < nck; ++k)
-        for (int j = 0; j < ncj; ++j)
-            for (int i = 0; i < nci; ++i)
+        const int ci = (int)(e % nci), cj = (int)((e / nci) % ncj), ck = (int)(e / ((long long)nci * ncj));
+        int b[6] = {ci, ci + 1, cj, cj + 1, ck, ck + 1};
+        float m = m0[e];
+        double sum = ksum[e];
+        long long cnt = kcnt[e];
+        int fails = 0, dir = 0;
+        while (fails < 6)
+        {
+            const int ax = dir >> 1, plus = dir & 1;
+            int ok = plus ? b[2 * ax + 1] < dims[ax] : b[2 * ax] > 0;
+            ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent;
+            if (ok)
             {
-                const size_t e = ((size_t)k * ncj + j) * nci + i;
-                const int lx = lvl[e] & 7, ly = (lvl[e] >> 3) & 7, lz = (lvl[e] >> 6) & 7;
-                const size_t oe = ((size_t)((k >> lz) << lz) * ncj + ((j >> ly) << ly)) * nci + ((i >> lx) << lx);
-                uint32_t bits;
-                const float m = rmax[oe];
-                memcpy(&bits, &m, 4);
-                bits = ((bits + 511u) & ~511u) | (uint32_t)lvl[e];
-                memcpy(&maj[2 * e], &bits, 4);
-                maj[2 * e + 1] = majorant_reciprocal(maj[2 * e]);
+                int l[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};        /* the new layer */
+                if (plus) { l[2 * ax] = b[2 * ax + 1]; l[2 * ax + 1] = b[2 * ax + 1] + 1; }
+                else { l[2 * ax] = b[2 * ax] - 1; l[2 * ax + 1] = b[2 * ax]; }
+                float lm = 0.0f;
+                double ls = 0.0;
+                long long lc = 0;
+                for (int kk = l[4]; kk < l[5]; ++kk)
+                    for (int jj = l[2]; jj < l[3]; ++jj)
+                        for (int ii = l[0]; ii < l[1]; ++ii)
+                        {
+                            const size_t q = ((size_t)kk * ncj + jj) * nci + ii;
+                            if (m0[q] > lm) lm = m0[q];
+                            ls += ksum[q];
+                            lc += kcnt[q];
+                        }
+                const float nm = lm > m ? lm : m;
+                const double nsum = sum + ls;
+                const long long ncnt = cnt + lc;
+                const double ex = (double)(b[1] - b[0] + (ax == 0 ? 1 : 0)) * h[0], ey = (double)(b[3] - b[2] + (ax == 1 ? 1 : 0)) * h[1],
+                             ez = (double)(b[5] - b[4] + (ax == 2 ? 1 : 0)) * h[2];
+                const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
+                ok = ((double)nm - nsum / (double)ncnt) * len <= (double)tau;
+                if (ok)
+                {
+                    if (plus) b[2 * ax + 1] += 1; else b[2 * ax] -= 1;
+                    m = nm; sum = nsum; cnt = ncnt;
+                }
             }
-    free(rmax); free(rsum); free(rcnt);
+            fails = ok ? 0 : fails + 1;
+            dir = dir == 5 ? 0 : dir + 1;
+        }
+        box[e] = (uint32_t)(ci - b[0]) | ((uint32_t)(b[1] - 1 - ci) << 5) | ((uint32_t)(cj - b[2]) << 10)
+                 | ((uint32_t)(b[3] - 1 - cj) << 15) | ((uint32_t)(ck - b[4]) << 20) | ((uint32_t)(b[5] - 1 - ck) << 25);
+        maj[2 * e] = m;
+        maj[2 * e + 1] = region_reciprocal(m);
+    }
 }
 
 /* Restates raytracer_kernels.cu:263-305 (cloud bounds: levels with any asy > 0) and
@@ -424,7 +416,7 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
 
     /* majorant grid of the cloud slab */
     out->gslab = -1; out->nci = out->ncj = out->nck = 0; out->hx = out->hy = out->hz = 0.0f; out->maj = NULL;
-    out->lvl = NULL;
+    out->box = NULL;
     if (g >= 0 && sc->sx > 0 && sc->sy > 0 && sc->sz > 0)
     {
         const int nci = (sc->itot + sc->sx - 1) / sc->sx, ncj = (sc->jtot + sc->sy - 1) / sc->sy;
@@ -432,7 +424,8 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
         out->gslab = g; out->nci = nci; out->ncj = ncj; out->nck = nck;
         out->hx = (float)sc->sx * sc->dx; out->hy = (float)sc->sy * sc->dy; out->hz = (float)sc->sz * sc->dz;
         out->maj = (float*)malloc(sizeof(float) * 2 * (size_t)nci * ncj * nck);
-        out->lvl = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)nci * ncj * nck);
+        out->box = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)nci * ncj * nck);
+        float* m0 = (float*)malloc(sizeof(float) * (size_t)nci * ncj * nck);
         double* ksum = (double*)malloc(sizeof(double) * (size_t)nci * ncj * nck);
         int* kcnt = (int*)malloc(sizeof(int) * (size_t)nci * ncj * nck);
         for (int ck = 0; ck < nck; ++ck)
@@ -456,14 +449,13 @@ void oracle_build_slabs(const oracle_scene_t* sc, const float* k_gas, const floa
                                 ++cnt;
                             }
                     const size_t e = ((size_t)ck * ncj + cj) * nci + ci;
-                    out->maj[2 * e] = m;
-                    out->maj[2 * e + 1] = majorant_reciprocal(m);
+                    m0[e] = m;
                     ksum[e] = sum;
                     kcnt[e] = cnt;
                 }
-        build_regions(nci, ncj, nck, sc->levels > 0 ? sc->levels : 0, out->maj, ksum, kcnt, out->hx, out->hy, out->hz,
-                      sc->merge_tau, out->lvl);
-        free(ksum); free(kcnt);
+        build_boxes(nci, ncj, nck, 1 << (sc->levels > 0 ? sc->levels : 0), m0, ksum, kcnt, out->hx, out->hy, out->hz,
+                    sc->merge_tau, out->maj, out->box);
+        free(ksum); free(kcnt); free(m0);
     }
 }
 
@@ -591,20 +583,16 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         /* ---- traverse one majorant region ---- */
         const int gridded = slab == g;
         float M, invM, tx, ty, tz, fz;
-        /* the region: the aligned box of 2^Lx x 2^Ly x 2^Lz supervoxels around (ci, cj, ck), clipped at the grid */
-        int Lx = 0, Ly = 0, Lz = 0;
+        /* the region: the supervoxel's own box around (ci, cj, ck) */
+        uint32_t eb = 0u;
         size_t e = 0;
         if (gridded)
         {
             e = ((size_t)ck * ncj + cj) * nci + ci;
-            uint32_t mbits;
-            memcpy(&mbits, &sl->maj[2 * e], 4);
-            Lx = (int)(mbits & 7u); Ly = (int)((mbits >> 3) & 7u); Lz = (int)((mbits >> 6) & 7u);
+            eb = sl->box[e];
         }
-        const int L = Lx | Ly | Lz;
-        const int bx0 = (ci >> Lx) << Lx, by0 = (cj >> Ly) << Ly, bz0 = (ck >> Lz) << Lz;
-        const int bx1 = bx0 + (1 << Lx) < nci ? bx0 + (1 << Lx) : nci, by1 = by0 + (1 << Ly) < ncj ? by0 + (1 << Ly) : ncj,
-                  bz1 = bz0 + (1 << Lz) < nck ? bz0 + (1 << Lz) : nck;
+        const int bx0 = ci - (int)(eb & 31u), by0 = cj - (int)((eb >> 10) & 31u), bz0 = ck - (int)((eb >> 20) & 31u);
+        const int bx1 = ci + 1 + (int)((eb >> 5) & 31u), by1 = cj + 1 + (int)((eb >> 15) & 31u), bz1 = ck + 1 + (int)(eb >> 25);
         const float xlo = (float)bx0 * hx, xhi = (bx1 == nci) ? xs : (float)bx1 * hx;
         const float ylo = (float)by0 * hy, yhi = (by1 == ncj) ? ys : (float)by1 * hy;
         const float fx = iux > 0.0f ? xhi : xlo, fy = iuy > 0.0f ? yhi : ylo;
@@ -629,13 +617,17 @@ static void trace_one(const oracle_scene_t* sc, const oracle_slabs_t* sl,
         const float tt = hit ? t_exit : dn;
         x = fmaf(ux, tt, x); y = fmaf(uy, tt, y); z = fmaf(uz, tt, z);
         if (!gridded) { x = wrap_periodic(x, xs, inv_xs); y = wrap_periodic(y, ys, inv_ys); }
-        if (L > 0)
+        if (eb != 0u)
         {
-            /* inside a merged region the supervoxel indices follow the position (kept within the region:
-             * a coordinate that sits on one of its faces may round to the neighbour's side) */
-            ci = cell_of(x, inv_hx, nci); ci = ci < bx0 ? bx0 : (ci > bx1 - 1 ? bx1 - 1 : ci);
-            cj = cell_of(y, inv_hy, ncj); cj = cj < by0 ? by0 : (cj > by1 - 1 ? by1 - 1 : cj);
-            ck = (int)((z - zc0) * inv_hz); ck = ck < bz0 ? bz0 : (ck > bz1 - 1 ? bz1 - 1 : ck);
+            /* inside a box the supervoxel indices follow the position, within the box and never back along an axis:
+             * the motion is monotone on each axis, a coordinate that sits on a face may round to either side, and
+             * the box of the supervoxel behind a face reaches back over it */
+            const int lx0 = iux > 0.0f ? ci : bx0, lx1 = iux > 0.0f ? bx1 - 1 : ci;
+            const int ly0 = iuy > 0.0f ? cj : by0, ly1 = iuy > 0.0f ? by1 - 1 : cj;
+            const int lz0 = iuz > 0.0f ? ck : bz0, lz1 = iuz > 0.0f ? bz1 - 1 : ck;
+            ci = cell_of(x, inv_hx, nci); ci = ci < lx0 ? lx0 : ci; ci = ci > lx1 ? lx1 : ci;
+            cj = cell_of(y, inv_hy, ncj); cj = cj < ly0 ? ly0 : cj; cj = cj > ly1 ? ly1 : cj;
+            ck = (int)((z - zc0) * inv_hz); ck = ck < lz0 ? lz0 : ck; ck = ck > lz1 ? lz1 : ck;
         }
 
         if (hit)

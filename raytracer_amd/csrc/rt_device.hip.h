@@ -155,6 +155,15 @@ __device__ __forceinline__ float rt_rcp(float x)
     return r;
 }
 
+// 1/M of a majorant region as the traverse steps take it from M: the IEEE quotient for M >= 2^-100 (rt_rcp is exact
+// up to 2^100; the pre-pass refuses larger extinctions), FLT_MAX below -- finite, so that tau * (1/M) is a number for
+// tau == 0 too (a region without any extinction: tau == 0 then stops the photon for a collision test that is null,
+// any tau > 0 carries it through)
+__device__ __forceinline__ float region_reciprocal(float m)
+{
+    return m >= 0x1p-100f ? rt_rcp(m) : 3.4028234663852886e38f;
+}
+
 // x^(-1/3) of a positive normal float: bit-shift seed (4 % off), three division-free Newton steps
 // y <- y (4 - x y^3) / 3; 2 ulp
 __device__ __forceinline__ float rt_inv_cbrt(float x)

@@ -576,11 +576,11 @@ rt_trace_kernel(const TraceArgs a)
                     const bool gridded = slab == a.gslab;
                     const uint32_t e = gridded ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : a.ncoarse + (uint32_t)slab;
                     const float2 mm = a.maj[e];
-                    // the region: the aligned box of 2^Lx x 2^Ly x 2^Lz supervoxels around (ci, cj, ck)
-                    const uint32_t lb = gridded ? __float_as_uint(mm.x) : 0u;
-                    const int Lx = (int)(lb & 7u), Ly = (int)((lb >> 3) & 7u), Lz = (int)((lb >> 6) & 7u), L = Lx | Ly | Lz;
-                    const int bx0 = (ci >> Lx) << Lx, by0 = (cj >> Ly) << Ly, bz0 = (ck >> Lz) << Lz;
-                    const int bx1 = min(bx0 + (1 << Lx), a.nci), by1 = min(by0 + (1 << Ly), a.ncj), bz1 = min(bz0 + (1 << Lz), a.nck);
+                    // the region: the supervoxel's own box around (ci, cj, ck) (rt_boxes_kernel); a slab's entry holds 1/M
+                    const uint32_t eb = gridded ? __float_as_uint(mm.y) : 0u;
+                    const float inv_mm = gridded ? region_reciprocal(mm.x) : mm.y;
+                    const int bx0 = ci - (int)(eb & 31u), by0 = cj - (int)((eb >> 10) & 31u), bz0 = ck - (int)((eb >> 20) & 31u);
+                    const int bx1 = ci + 1 + (int)((eb >> 5) & 31u), by1 = cj + 1 + (int)((eb >> 15) & 31u), bz1 = ck + 1 + (int)(eb >> 25);
                     // the face ahead on each axis: index of the cell face, then its coordinate
                     const int cfx = iux > 0.0f ? bx1 : bx0, cfy = iuy > 0.0f ? by1 : by0;
                     const float fx = cfx == a.nci ? a.xs : (float)cfx * a.hx;
@@ -603,20 +603,20 @@ rt_trace_kernel(const TraceArgs a)
                     float t_exit = tx; int axis = gridded ? 0 : 2;      // a clear-air slab has only its z faces
                     if (ty < t_exit) { t_exit = ty; axis = 1; }
                     if (tz < t_exit) { t_exit = tz; axis = 2; }
-                    const float dn = tau * mm.y;          // raytracer_kernels.cu:367; 1/M is finite in the tables
+                    const float dn = tau * inv_mm;        // raytracer_kernels.cu:367; 1/M is finite
                     const bool hit = t_exit <= dn;
                     const float tt = hit ? t_exit : dn;
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z);
                     if (!gridded) { x = wrap_periodic(x, a.xs, a.inv_xs); y = wrap_periodic(y, a.ys, a.inv_ys); }
-                    if (L > 0)
+                    if (eb != 0u)
                     {
-                        // inside a merged region the supervoxel indices follow the position (kept within the
-                        // region: a coordinate on one of its faces may round to the neighbour's side)
-                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1);
-                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1);
-                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1);
+                        // inside a box the supervoxel indices follow the position, within the box and never back along
+                        // an axis (see RT_TRAVERSE_STEP)
+                        ci = min(max(cell_of(x, a.inv_hx, a.nci), iux > 0.0f ? ci : bx0), iux > 0.0f ? bx1 - 1 : ci);
+                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), iuy > 0.0f ? cj : by0), iuy > 0.0f ? by1 - 1 : cj);
+                        ck = min(max((int)((z - a.zc0) * a.inv_hz), up ? ck : bz0), up ? bz1 - 1 : ck);
                     }
-                    inv_m = mm.y;
+                    inv_m = inv_mm;
 
                     if (!hit)
                         state = ST_COLLIDE;
@@ -807,12 +807,14 @@ constexpr int kPoolBlock = 64;
                     const float2 mm = (MM); \
                     __builtin_amdgcn_s_setprio(0); \
                     int bx0 = ci, by0 = cj, bz0 = ck, bx1 = ci + 1, by1 = cj + 1, bz1 = ck + 1; \
+                    const float inv_m = region_reciprocal(mm.x); \
                     if (HIER) \
                     { \
-                        const uint32_t lb = __float_as_uint(mm.x); \
-                        const int Lx = (int)(lb & 7u), Ly = (int)((lb >> 3) & 7u), Lz = (int)((lb >> 6) & 7u); \
-                        bx0 = (ci >> Lx) << Lx; by0 = (cj >> Ly) << Ly; bz0 = (ck >> Lz) << Lz; \
-                        bx1 = min(bx0 + (1 << Lx), a.nci); by1 = min(by0 + (1 << Ly), a.ncj); bz1 = min(bz0 + (1 << Lz), a.nck); \
+                        /* the supervoxel's own box (rt_boxes_kernel): six extents of 5 bits */ \
+                        const uint32_t eb = __float_as_uint(mm.y); \
+                        bx0 = ci - (int)(eb & 31u); bx1 = ci + 1 + (int)((eb >> 5) & 31u); \
+                        by0 = cj - (int)((eb >> 10) & 31u); by1 = cj + 1 + (int)((eb >> 15) & 31u); \
+                        bz0 = ck - (int)((eb >> 20) & 31u); bz1 = ck + 1 + (int)(eb >> 25); \
                     } \
                     const bool px = (IX) > 0.0f, py = (IY) > 0.0f, up = (IZ) > 0.0f; \
                     const int cfx = px ? bx1 : bx0, cfy = py ? by1 : by0, cfz = up ? bz1 : bz0; \
@@ -826,21 +828,23 @@ constexpr int kPoolBlock = 64;
                     const float txy = y_first ? ty : tx; \
                     const bool z_first = tz < txy; \
                     const float t_exit = z_first ? tz : txy; \
-                    const float dn = tau * mm.y; \
+                    const float dn = tau * inv_m; \
                     const bool hit = t_exit <= dn; \
                     const float tt = hit ? t_exit : dn; \
                     x = fma_(ux, tt, x); y = fma_(uy, tt, y); z = fma_(uz, tt, z); \
                     if (HIER) \
                     { \
-                        /* inside a merged region the indices follow the position; for a region of one supervoxel */ \
-                        /* the clamp to [b0, b1 - 1] returns the index itself */ \
-                        ci = min(max(cell_of(x, a.inv_hx, a.nci), bx0), bx1 - 1); \
-                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), by0), by1 - 1); \
-                        ck = min(max((int)((z - a.zc0) * a.inv_hz), bz0), bz1 - 1); \
+                        /* inside a box the indices follow the position, within the box and never back along an axis */ \
+                        /* (the motion is monotone on each axis; a coordinate that sits on a face may round to either */ \
+                        /* side, and the box of the supervoxel behind the face reaches back over it); for a box of one */ \
+                        /* supervoxel the clamp returns the index itself */ \
+                        ci = min(max(cell_of(x, a.inv_hx, a.nci), px ? ci : bx0), px ? bx1 - 1 : ci); \
+                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), py ? cj : by0), py ? by1 - 1 : cj); \
+                        ck = min(max((int)((z - a.zc0) * a.inv_hz), up ? ck : bz0), up ? bz1 - 1 : ck); \
                     } \
                     /* a face: carry tau on, step over the face (periodic in x and y); no face: 1/M rides in tau */ \
                     const float tau_on = fma_(-tt, mm.x, tau); \
-                    tau = hit ? (tau_on > 0.0f ? tau_on : 0.0f) : mm.y; \
+                    tau = hit ? (tau_on > 0.0f ? tau_on : 0.0f) : inv_m; \
                     const bool hit_x = hit && !y_first && !z_first, hit_y = hit && y_first && !z_first, hit_z = hit && z_first; \
                     int ni = px ? bx1 : bx0 - 1, nj = py ? by1 : by0 - 1; \
                     float nx = fx, ny = fy; \
@@ -1209,10 +1213,19 @@ rt_trace_pool_kernel(const PoolArgs a)
                     // the stage's scalar argument loads are issued in one batch instead of one per basic block)
                     const int i = cell_of(g0.x, k->inv_dx, k->itot), j = cell_of(g0.y, k->inv_dy, k->jtot);
                     const uint32_t kz = (uint32_t)cell_of(g0.z, k->inv_dz, k->ktot);
+#if RT_BRICK == 0
+                    // plain [k][j][i] records: the cell's record and its tally word share their index arithmetic
+                    // (+0.25 % on C4; doing these multiplies and the majorant index's with 24-bit operands, where the grid
+                    // allows it, would give another 0.2 %: not worth a second code path)
+                    const uint32_t ij = (uint32_t)j * (uint32_t)k->itot + (uint32_t)i, kcol = kz * k->ncol;
+                    cr = k->cells[ij + kcol];
+                    cell = ij + (on_surface ? 0u : kcol);       // the [k][j][i] index, for the absorption tally
+#else
                     cr = k->cells[brick_index((uint32_t)i, (uint32_t)j, kz, k->nbi, k->nbij)];
                     cell = (uint32_t)i + (uint32_t)j * (uint32_t)k->itot;
-                    inv_m = g0.w;
                     cell += (on_surface ? 0u : kz) * k->ncol;   // the [k][j][i] index, for the absorption tally
+#endif
+                    inv_m = g0.w;
                     mm_pre = a.maj[slab == a.gslab ? (uint32_t)((ck * a.ncj + cj) * a.nci + ci) : 0u];
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -1556,6 +1569,86 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, d
     maj[e] = make_float2(m, 1.0f / m);
     ksum[e] = sum;
     kcnt[e] = cnt;
+}
+
+// Majorant regions over the supervoxel grid: every supervoxel gets a BOX OF ITS OWN -- the supervoxels
+// [ci - xm, ci + xp] x [cj - ym, cj + yp] x [ck - zm, ck + zp] around it, clipped at the grid, at most max_extent per
+// axis -- that a photon standing in it crosses as ONE region under the box's majorant. The boxes of neighbouring
+// supervoxels overlap; they are no partition of the grid and need not be: each step of the walk is made under a
+// majorant that bounds the extinction over the whole segment, which is all that null-collision tracking asks for (the
+// optical depth carried over a face is decremented with the same majorant the segment was sampled with). Round 3's
+// first regions were the aligned boxes of a buddy merge (2^lx x 2^ly x 2^lz supervoxels): a photon in clear air then
+// crosses the faces of a binary partition wherever it goes (8.2 crossings per photon on the LES grid); with a box grown
+// AROUND the supervoxel it is in, it goes to the nearest cloud edge or box limit in one step (4.8).
+// Growth: from the supervoxel alone, one layer at a time, trying the six faces in turn (x-, x+, y-, y+, z-, z+) until
+// six attempts in a row have failed; a layer is taken if (M - mean k_tot) * len <= tau for the grown box, M its
+// majorant, mean its volume mean and len = 6 V / S (the box's edge for a cube, three times the thickness of a wide
+// slab): the optical depth of null collisions a crossing photon meets. One THREAD per supervoxel, the layer's cells
+// in (k, j, i) order, sums in double: the oracle's copy of this routine must decide identically.
+// out[e] = {M of the box, the six extents in 5 bits each: xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25}.
+__global__ void __launch_bounds__(64)
+rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum, const int* __restrict__ kcnt,
+                float2* __restrict__ out, unsigned int* __restrict__ any_box, uint32_t ncoarse, int nci, int ncj, int nck,
+                float hx, float hy, float hz, float tau, int max_extent)
+{
+    const uint32_t e = blockIdx.x * 64u + threadIdx.x;
+    if (e >= ncoarse)
+        return;
+    const int dims[3] = {nci, ncj, nck};
+    const double h[3] = {(double)hx, (double)hy, (double)hz};
+    int b[6];
+    b[0] = (int)(e % (uint32_t)nci); b[2] = (int)((e / (uint32_t)nci) % (uint32_t)ncj); b[4] = (int)(e / ((uint32_t)nci * (uint32_t)ncj));
+    const int ci = b[0], cj = b[2], ck = b[4];
+    b[1] = b[0] + 1; b[3] = b[2] + 1; b[5] = b[4] + 1;
+    float m = maj0[e].x;
+    double sum = ksum[e];
+    long long cnt = kcnt[e];
+    int fails = 0, dir = 0;
+    while (fails < 6)
+    {
+        const int ax = dir >> 1;
+        const bool plus = dir & 1;
+        bool ok = plus ? b[2 * ax + 1] < dims[ax] : b[2 * ax] > 0;
+        ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent;
+        if (ok)
+        {
+            int l[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};        // the new layer
+            if (plus) { l[2 * ax] = b[2 * ax + 1]; l[2 * ax + 1] = b[2 * ax + 1] + 1; }
+            else { l[2 * ax] = b[2 * ax] - 1; l[2 * ax + 1] = b[2 * ax]; }
+            float lm = 0.0f;
+            double ls = 0.0;
+            long long lc = 0;
+            for (int kk = l[4]; kk < l[5]; ++kk)
+                for (int jj = l[2]; jj < l[3]; ++jj)
+                    for (int ii = l[0]; ii < l[1]; ++ii)
+                    {
+                        const uint32_t q = (uint32_t)((kk * ncj + jj) * nci + ii);
+                        const float v = maj0[q].x;
+                        lm = v > lm ? v : lm;
+                        ls += ksum[q];
+                        lc += kcnt[q];
+                    }
+            const float nm = lm > m ? lm : m;
+            const double nsum = sum + ls;
+            const long long ncnt = cnt + lc;
+            const double ex = (double)(b[1] - b[0] + (ax == 0 ? 1 : 0)) * h[0], ey = (double)(b[3] - b[2] + (ax == 1 ? 1 : 0)) * h[1],
+                         ez = (double)(b[5] - b[4] + (ax == 2 ? 1 : 0)) * h[2];
+            const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
+            ok = ((double)nm - nsum / (double)ncnt) * len <= (double)tau;
+            if (ok)
+            {
+                if (plus) b[2 * ax + 1] += 1; else b[2 * ax] -= 1;
+                m = nm; sum = nsum; cnt = ncnt;
+            }
+        }
+        fails = ok ? 0 : fails + 1;
+        dir = dir == 5 ? 0 : dir + 1;
+    }
+    const uint32_t ext = (uint32_t)(ci - b[0]) | ((uint32_t)(b[1] - 1 - ci) << 5) | ((uint32_t)(cj - b[2]) << 10)
+                         | ((uint32_t)(b[3] - 1 - cj) << 15) | ((uint32_t)(ck - b[4]) << 20) | ((uint32_t)(b[5] - 1 - ck) << 25);
+    out[e] = make_float2(m, __uint_as_float(ext));
+    if (ext != 0u)
+        *any_box = 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1994,7 +2087,6 @@ struct rt_context
 
     float4* d_cells = nullptr;        // {k_tot, ssa, asy, k_cloud} per cell
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
-    uint16_t* d_lvl = nullptr;        // region levels lx | ly << 3 | lz << 6 per supervoxel
     int levels = -1;                  // largest region: boxes of up to 2^levels supervoxels per edge (0 = no merging,
                                       // -1 = automatic: RT_AUTO_LEVELS or 0)
     int merge_tau_milli = 1000;       // merge criterion: (M - mean k_tot) * 6 V / S <= merge_tau_milli / 1000
@@ -2094,88 +2186,6 @@ void build_slabs(rt_context* c)
     for (int i = n + 1; i < 4; ++i) s.zface[i] = s.zface[n];
 }
 
-// (Re)builds the majorant table on the device: supervoxels of the cloud slab (if the grid is
-// enabled and a cloud slab exists), followed by one {M, 1/M} entry per slab.
-// Majorant regions over the supervoxel grid (host side of the pre-pass): aligned BOXES of 2^lx x 2^ly x 2^lz
-// supervoxels (clipped at the grid), grown bottom-up by merging buddies. Sweep s works on axis s mod 3 (x, y, z in
-// turn) at level t = s / 3: a region whose level along that axis is t and whose origin has bit t of that coordinate
-// clear merges with its buddy -- the region of the same shape 2^t supervoxels further along the axis -- if
-// (M - mean k_tot) * len <= tau, len = 6 V / S of the merged box (its edge for a cube, three times the thickness of a
-// wide slab): the optical depth of null collisions a crossing photon meets. A buddy outside the grid merges
-// trivially. Growing the axes in turn gives cubes where the field is homogeneous all around (round 2's regions were
-// cubes only: 10.3 face crossings per photon on the LES grid) and boxes that go on along one or two axes where the
-// others are blocked: tall columns of clear air between clouds, flat layers under and over them.
-// maj: pairs {M, 1/M} per supervoxel in, per region out. Double arithmetic in a fixed order: the oracle's
-// copy of this routine must decide identically. lvl[e] = lx | ly << 3 | lz << 6.
-void build_regions(int nci, int ncj, int nck, int max_level, std::vector<float2>& maj, const std::vector<double>& ksum,
-                   const std::vector<int>& kcnt, float hx, float hy, float hz, float tau, std::vector<uint16_t>& lvl)
-{
-    const size_t n = (size_t)nci * ncj * nck;
-    const int dims[3] = {nci, ncj, nck};
-    const double h[3] = {(double)hx, (double)hy, (double)hz};
-    std::fill(lvl.begin(), lvl.end(), (uint16_t)0);
-    std::vector<float> rmax(n);              // per region, kept at its origin supervoxel
-    std::vector<double> rsum(ksum);
-    std::vector<long long> rcnt(n);
-    for (size_t e = 0; e < n; ++e) { rmax[e] = maj[e].x; rcnt[e] = kcnt[e]; }
-    const auto at = [&](int i, int j, int k) { return ((size_t)k * ncj + j) * nci + i; };
-    for (int sweep = 0; sweep < 3 * max_level; ++sweep)
-    {
-        const int axis = sweep % 3, t = sweep / 3;
-        for (int k = 0; k < nck; ++k)
-            for (int j = 0; j < ncj; ++j)
-                for (int i = 0; i < nci; ++i)
-                {
-                    const size_t e = at(i, j, k);
-                    const int l[3] = {lvl[e] & 7, (lvl[e] >> 3) & 7, (lvl[e] >> 6) & 7};
-                    const int o[3] = {i, j, k};
-                    // origins of regions at level t along the axis, lower buddy only
-                    if (l[axis] != t || (i & ((1 << l[0]) - 1)) || (j & ((1 << l[1]) - 1)) || (k & ((1 << l[2]) - 1))) continue;
-                    if ((o[axis] >> t) & 1) continue;
-                    int bo[3] = {i, j, k};
-                    bo[axis] += 1 << t;
-                    int hi[3];          // clipped end of the merged box
-                    for (int d = 0; d < 3; ++d)
-                        hi[d] = std::min(o[d] + (1 << (l[d] + (d == axis ? 1 : 0))), dims[d]);
-                    if (bo[axis] < dims[axis])
-                    {
-                        const size_t be = at(bo[0], bo[1], bo[2]);
-                        if (lvl[be] != lvl[e]) continue;            // the buddy is not a region of the same shape
-                        const float m = rmax[be] > rmax[e] ? rmax[be] : rmax[e];
-                        const double sum = rsum[e] + rsum[be];
-                        const long long cnt = rcnt[e] + rcnt[be];
-                        const double ex = (double)(hi[0] - o[0]) * h[0], ey = (double)(hi[1] - o[1]) * h[1],
-                                     ez = (double)(hi[2] - o[2]) * h[2];
-                        const double len = 3.0 * (ex * ey * ez) / (ex * ey + ey * ez + ex * ez);
-                        if (((double)m - sum / (double)cnt) * len > (double)tau) continue;
-                        rmax[e] = m; rsum[e] = sum; rcnt[e] = cnt;
-                    }
-                    const uint16_t nl = (uint16_t)(lvl[e] + (1u << (3 * axis)));
-                    for (int kk = k; kk < hi[2]; ++kk)
-                        for (int jj = j; jj < hi[1]; ++jj)
-                            for (int ii = i; ii < hi[0]; ++ii)
-                                lvl[at(ii, jj, kk)] = nl;
-                }
-    }
-    // Every supervoxel takes its region's majorant (kept at the region's origin). The levels ride in the nine low
-    // mantissa bits of M, rounded UP to make room (still a majorant, larger by < 2^-14 of itself), and 1/M is taken
-    // from the packed value: one 8-byte table entry tells a traverse round everything about its region (a second
-    // table cost a second cache line per round).
-    for (int k = 0; k < nck; ++k)
-        for (int j = 0; j < ncj; ++j)
-            for (int i = 0; i < nci; ++i)
-            {
-                const size_t e = at(i, j, k);
-                const int lx = lvl[e] & 7, ly = (lvl[e] >> 3) & 7, lz = (lvl[e] >> 6) & 7;
-                const float m = rmax[at((i >> lx) << lx, (j >> ly) << ly, (k >> lz) << lz)];
-                uint32_t bits;
-                memcpy(&bits, &m, 4);
-                bits = ((bits + 511u) & ~511u) | (uint32_t)lvl[e];
-                memcpy(&maj[e].x, &bits, 4);
-                maj[e].y = majorant_reciprocal(maj[e].x);
-            }
-}
-
 // workgroups of the launch sort's count and scatter passes (two of 1024 threads fit a CU)
 #ifndef RT_SORT_BLOCKS_X2
 #define RT_SORT_BLOCKS_X2 4
@@ -2228,49 +2238,46 @@ int build_majorants(rt_context* c)
         if (c->d_maj) RT_HIP(hipFree(c->d_maj));
         c->d_maj = nullptr;
         RT_HIP(hipMalloc(&c->d_maj, sizeof(float2) * (ncoarse + 3)));
-        if (c->d_lvl) RT_HIP(hipFree(c->d_lvl));
-        c->d_lvl = nullptr;
-        RT_HIP(hipMalloc(&c->d_lvl, sizeof(uint16_t) * (ncoarse + 4)));
         c->maj_capacity = ncoarse + 3;
     }
+    c->hier = false;
     if (ncoarse)
     {
+        // per supervoxel: majorant, sum and number of cells; then every supervoxel's box (rt_boxes_kernel)
+        float2* d_maj0 = nullptr;
         double* d_ksum = nullptr;
         int* d_kcnt = nullptr;
-        hipError_t e = hipMalloc(&d_ksum, sizeof(double) * ncoarse);
+        unsigned int* d_any = nullptr;
+        unsigned int any = 0;
+        hipError_t e = hipMalloc(&d_maj0, sizeof(float2) * ncoarse);
+        if (e == hipSuccess) e = hipMalloc(&d_ksum, sizeof(double) * ncoarse);
         if (e == hipSuccess) e = hipMalloc(&d_kcnt, sizeof(int) * ncoarse);
+        if (e == hipSuccess) e = hipMalloc(&d_any, sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemsetAsync(d_any, 0, sizeof(unsigned int), c->stream);
         if (e == hipSuccess)
         {
-            hipLaunchKernelGGL(rt_majorant_kernel, dim3((unsigned)((ncoarse + 63) / 64)), dim3(64), 0, c->stream,
-                               c->d_cells, c->d_maj, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, c->nbi, c->nbij,
+            const dim3 grid((unsigned)((ncoarse + 63) / 64)), block(64);
+            hipLaunchKernelGGL(rt_majorant_kernel, grid, block, 0, c->stream,
+                               c->d_cells, d_maj0, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, c->nbi, c->nbij,
                                s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
+            hipLaunchKernelGGL(rt_boxes_kernel, grid, block, 0, c->stream, d_maj0, d_ksum, d_kcnt, c->d_maj, d_any,
+                               (uint32_t)ncoarse, s.nci, s.ncj, s.nck, s.hx, s.hy, s.hz,
+                               (float)((double)c->merge_tau_milli / 1000.0), 1 << levels);
             e = hipGetLastError();
         }
-        // merge supervoxels into regions (small: one entry per supervoxel), on the host
-        std::vector<float2> h_maj(ncoarse);
-        std::vector<double> h_ksum(ncoarse);
-        std::vector<int> h_kcnt(ncoarse);
-        std::vector<uint16_t> h_lvl(ncoarse);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_maj.data(), c->d_maj, sizeof(float2) * ncoarse, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_ksum.data(), d_ksum, sizeof(double) * ncoarse, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_kcnt.data(), d_kcnt, sizeof(int) * ncoarse, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&any, d_any, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (d_maj0) (void)hipFree(d_maj0);
         if (d_ksum) (void)hipFree(d_ksum);
         if (d_kcnt) (void)hipFree(d_kcnt);
+        if (d_any) (void)hipFree(d_any);
         RT_HIP(e);
-        build_regions(s.nci, s.ncj, s.nck, levels, h_maj, h_ksum, h_kcnt, s.hx, s.hy, s.hz,
-                      (float)((double)c->merge_tau_milli / 1000.0), h_lvl);
-        c->hier = false;
-        for (size_t i = 0; i < ncoarse && !c->hier; ++i) c->hier = h_lvl[i] > 0;
-        RT_HIP(hipMemcpyAsync(c->d_maj, h_maj.data(), sizeof(float2) * ncoarse, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(hipMemcpyAsync(c->d_lvl, h_lvl.data(), sizeof(uint16_t) * ncoarse, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(hipStreamSynchronize(c->stream));
+        c->hier = any != 0;
     }
     float2 slab_m[3];
     for (int i = 0; i < 3; ++i) slab_m[i] = make_float2(s.kmaj[i], c->inv_kmaj[i]);
     RT_HIP(hipMemcpyAsync(c->d_maj + ncoarse, slab_m, sizeof(slab_m), hipMemcpyHostToDevice, c->stream));
     RT_HIP(hipStreamSynchronize(c->stream));
-    if (!ncoarse) c->hier = false;
     c->ncoarse = ncoarse;
     c->maj_dirty = false;
     return RT_OK;
@@ -2999,7 +3006,6 @@ int rt_destroy(rt_context* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     if (c->d_cells) (void)hipFree(c->d_cells);
     if (c->d_maj) (void)hipFree(c->d_maj);
-    if (c->d_lvl) (void)hipFree(c->d_lvl);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->d_tallies && c->owns_tallies) (void)hipFree(c->d_tallies);
     if (c->d_tallies_alt) (void)hipFree(c->d_tallies_alt);
@@ -3157,7 +3163,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "levels"))
     {
-        if (value < -1 || value > 7) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,7]", value);
+        if (value < -1 || value > 5) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,5]", value);
         c->levels = (int)value;
         c->maj_dirty = true;
     }
@@ -3473,14 +3479,20 @@ int rt_get_majorants(rt_context* c, float* out_pairs, size_t n_pairs)
     }
     if (n_pairs != c->ncoarse)
         return fail(RT_ERR_ARG, "rt_get_majorants: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n_pairs);
-    if (n_pairs) RT_HIP(hipMemcpy(out_pairs, c->d_maj, sizeof(float2) * n_pairs, hipMemcpyDeviceToHost));
+    if (n_pairs)
+    {
+        // the table holds {M, extents of the supervoxel's box}; the steps take 1/M from M (region_reciprocal)
+        RT_HIP(hipMemcpy(out_pairs, c->d_maj, sizeof(float2) * n_pairs, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < n_pairs; ++e)
+            out_pairs[2 * e + 1] = out_pairs[2 * e] >= 0x1p-100f ? 1.0f / out_pairs[2 * e] : FLT_MAX;
+    }
     return RT_OK;
 }
 
-int rt_get_region_levels(rt_context* c, uint16_t* out, size_t n)
+int rt_get_region_boxes(rt_context* c, uint32_t* out, size_t n)
 {
-    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_region_levels: null argument");
-    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_region_levels: call rt_upload_optics first");
+    if (!c || !out) return fail(RT_ERR_ARG, "rt_get_region_boxes: null argument");
+    if (!c->have_optics) return fail(RT_ERR_STATE, "rt_get_region_boxes: call rt_upload_optics first");
     RT_HIP(hipSetDevice(c->device));
     if (c->maj_dirty)
     {
@@ -3488,8 +3500,14 @@ int rt_get_region_levels(rt_context* c, uint16_t* out, size_t n)
         if (rc != RT_OK) return rc;
     }
     if (n != c->ncoarse)
-        return fail(RT_ERR_ARG, "rt_get_region_levels: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n);
-    if (n) RT_HIP(hipMemcpy(out, c->d_lvl, sizeof(uint16_t) * n, hipMemcpyDeviceToHost));
+        return fail(RT_ERR_ARG, "rt_get_region_boxes: the grid has %zu supervoxels, caller asked for %zu", c->ncoarse, n);
+    if (n)
+    {
+        std::vector<float2> h(n);
+        RT_HIP(hipMemcpy(h.data(), c->d_maj, sizeof(float2) * n, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < n; ++e)
+            memcpy(&out[e], &h[e].y, sizeof(uint32_t));
+    }
     return RT_OK;
 }
 

@@ -94,7 +94,7 @@ def load_library():
         "rt_tallies_widen": (C.c_int, [vp, vp, vp]),
         "rt_get_slabs": (C.c_int, [vp, C.POINTER(SlabInfo)]),
         "rt_get_majorants": (C.c_int, [vp, f32p, C.c_size_t]),
-        "rt_get_region_levels": (C.c_int, [vp, C.POINTER(C.c_uint16), C.c_size_t]),
+        "rt_get_region_boxes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_size_t]),
         "rt_get_events": (C.c_int, [vp, u64p]),
         "rt_get_sched_stats": (C.c_int, [vp, u64p]),
         "rt_last_trace_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -297,15 +297,17 @@ class PhotonTracer:
         _check(self.lib.rt_get_majorants(self._h, _f32p(out), n))
         return out
 
-    def region_levels(self):
-        """Region levels of every supervoxel, uint16 [nck, ncj, nci] (or None), lx | ly << 3 | lz << 6: supervoxels are
-        merged into aligned boxes of 2^lx x 2^ly x 2^lz supervoxels; majorants() holds the region's pair."""
+    def region_boxes(self):
+        """The majorant box of every supervoxel, uint32 [nck, ncj, nci] (or None): six extents of 5 bits,
+        xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25 -- a photon in supervoxel (ci, cj, ck) crosses the
+        supervoxels [ci - xm, ci + xp] x [cj - ym, cj + yp] x [ck - zm, ck + zp] as one region; majorants() holds
+        the box's pair."""
         s = self.slabs()
         n = s.nci * s.ncj * s.nck
         if n == 0:
             return None
-        out = np.zeros((s.nck, s.ncj, s.nci), dtype=np.uint16)
-        _check(self.lib.rt_get_region_levels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16)), n))
+        out = np.zeros((s.nck, s.ncj, s.nci), dtype=np.uint32)
+        _check(self.lib.rt_get_region_boxes(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
         return out
 
     def launch_positions(self, seed, photon_id_begin, n):

@@ -37,7 +37,7 @@ class OracleSlabs(C.Structure):
                 ("inv_kmaj", C.c_float * 3), ("k_lo", C.c_int), ("k_hi", C.c_int),
                 ("sun", C.c_float * 3), ("gslab", C.c_int), ("nci", C.c_int), ("ncj", C.c_int), ("nck", C.c_int),
                 ("hx", C.c_float), ("hy", C.c_float), ("hz", C.c_float), ("maj", C.POINTER(C.c_float)),
-                ("lvl", C.POINTER(C.c_uint16))]
+                ("box", C.POINTER(C.c_uint32))]
 
 
 _lib = None
@@ -157,14 +157,14 @@ def sobol_words(seed, pids, shifted=True):
 
 def oracle_slabs(scene, supergrid=DEFAULT_SUPERGRID, levels=DEFAULT_LEVELS, merge_tau=DEFAULT_MERGE_TAU) -> OracleSlabs:
     """Slabs + majorant grid; `.maj_array` holds a copy of the {M, 1/M} pairs [nck, ncj, nci, 2] and
-    `.lvl_array` the region levels [nck, ncj, nci]."""
+    `.box_array` the supervoxels' boxes (six extents of 5 bits) [nck, ncj, nci]."""
     sc = oracle_scene(scene, supergrid=supergrid, levels=levels, merge_tau=merge_tau)
     sl = OracleSlabs()
     kg, kc, _, asy = [np.ascontiguousarray(a, dtype=np.float32) for a in scene.fields()]
     lib().oracle_build_slabs(C.byref(sc), _p(kg, C.c_float), _p(kc, C.c_float), _p(asy, C.c_float), C.byref(sl))
     n = sl.nci * sl.ncj * sl.nck
     sl.maj_array = np.ctypeslib.as_array(sl.maj, shape=(2 * n,)).copy().reshape(sl.nck, sl.ncj, sl.nci, 2) if n else None
-    sl.lvl_array = np.ctypeslib.as_array(sl.lvl, shape=(n,)).copy().reshape(sl.nck, sl.ncj, sl.nci) if n else None
+    sl.box_array = np.ctypeslib.as_array(sl.box, shape=(n,)).copy().reshape(sl.nck, sl.ncj, sl.nci) if n else None
     lib().oracle_free_slabs(C.byref(sl))
     return sl
 

@@ -138,10 +138,10 @@ def _check_structures(tr, scene, supergrid):
     assert (sl.hx, sl.hy, sl.hz) == (osl.hx, osl.hy, osl.hz)
     maj = tr.majorants()
     if osl.maj_array is None:
-        assert maj is None and tr.region_levels() is None
+        assert maj is None and tr.region_boxes() is None
     else:
         assert np.array_equal(maj.view(np.uint32), osl.maj_array.view(np.uint32))
-        assert np.array_equal(tr.region_levels(), osl.lvl_array)
+        assert np.array_equal(tr.region_boxes(), osl.box_array)
 
 
 @pytest.mark.parametrize("scene_name,n,supergrid", [
@@ -288,18 +288,34 @@ def test_planar_mode_bit_identical_to_oracle(rt, n, supergrid):
     ("cumulus_small", 1 << 17, (4, 4, 2), 4, 37), ("tiny", 1 << 16, (1, 1, 1), 3, 500), ("tiny", 1 << 16, (5, 3, 2), 1, 100000),
     ("cloud_to_top", 1 << 15, (4, 4, 1), 2, 500), ("rayleigh_absorbing", 1 << 16, (8, 8, 4), 4, 500)])
 def test_region_hierarchy_bit_identical_to_oracle(rt, pool, scene_name, n, supergrid, levels, tau_milli):
-    """Supervoxels merged bottom-up into aligned boxes of up to 2^levels per edge (each axis on its own) where
-    (M - mean k) * 6 V / S <= tau (options "levels", "merge_tau_milli"): fewer, larger majorant regions away from
-    cloud edges. The levels, the region majorants and every tally must equal the oracle's."""
+    """Every supervoxel's own majorant box, grown a layer at a time up to 2^levels supervoxels per axis while
+    (M - mean k) * 6 V / S <= tau (options "levels", "merge_tau_milli"): fewer, longer steps away from cloud edges.
+    The boxes (built by a kernel in the library, by a loop in the oracle), their majorants and every tally must equal
+    the oracle's; a box contains its supervoxel, stays inside the grid and within the extent asked for, and its
+    majorant bounds every supervoxel in it."""
     scene = SCENES[scene_name](rt.scenes)
     tr = rt.PhotonTracer.from_scene(scene, stats=1, pool=pool, levels=levels, merge_tau_milli=tau_milli)
     tr.set_supergrid(*supergrid)
     tau = np.float32(tau_milli / 1000.0)
     osl = O.oracle_slabs(scene, supergrid=supergrid, levels=levels, merge_tau=tau)
-    if osl.lvl_array is not None:
-        assert np.array_equal(tr.region_levels(), osl.lvl_array)
-        assert max(int(((osl.lvl_array >> sh) & 7).max()) for sh in (0, 3, 6)) <= levels
+    if osl.box_array is not None:
+        box = tr.region_boxes()
+        assert np.array_equal(box, osl.box_array)
         assert np.array_equal(tr.majorants().view(np.uint32), osl.maj_array.view(np.uint32))
+        ext = [((box >> sh) & 31).astype(np.int64) for sh in range(0, 30, 5)]        # xm, xp, ym, yp, zm, zp
+        idx = np.meshgrid(np.arange(osl.nck), np.arange(osl.ncj), np.arange(osl.nci), indexing="ij")
+        for ax, (lo, hi, dim) in enumerate(((ext[0], ext[1], osl.nci), (ext[2], ext[3], osl.ncj), (ext[4], ext[5], osl.nck))):
+            c = idx[2 - ax]
+            assert (c - lo >= 0).all() and (c + hi < dim).all() and int((lo + hi + 1).max()) <= (1 << levels)
+        if levels == 0:
+            assert not box.any()
+        base = O.oracle_slabs(scene, supergrid=supergrid, levels=0, merge_tau=tau).maj_array[..., 0]
+        rng = np.random.default_rng(1)
+        for _ in range(200):        # the majorant of a box bounds every supervoxel in it
+            k, j, i = (int(rng.integers(0, d)) for d in (osl.nck, osl.ncj, osl.nci))
+            sub = base[k - ext[4][k, j, i]:k + ext[5][k, j, i] + 1, j - ext[2][k, j, i]:j + ext[3][k, j, i] + 1,
+                       i - ext[0][k, j, i]:i + ext[1][k, j, i] + 1]
+            assert float(sub.max()) == float(osl.maj_array[k, j, i, 0])
     tr.trace(99, 123_456_789_000, n); tr.synchronize()
     want, ev = O.photon_oracle(scene, 99, 123_456_789_000, n, supergrid=supergrid, levels=levels, merge_tau=tau)
     _assert_same(tr.tallies(), want)
@@ -386,14 +402,14 @@ def gas_free_scene(S):
 
 @pytest.mark.parametrize("pool", [0, 128])
 def test_regression_zero_majorant_region_with_zero_optical_depth(rt, pool):
-    """A merged region without extinction has M = 0 with the region level in its low mantissa bits (a denormal)
-    and once had 1/M = +inf in the table: a photon entering it with tau == 0 (one launch in 2^24) computed
-    0 * inf = NaN and was 'absorbed' in cell 0. 1/M is finite now (FLT_MAX): such a photon takes a null collision
-    where it stands and goes on. The four photons below draw tau == 0 at launch."""
+    """A region without extinction has M = 0 and once had 1/M = +inf in the table: a photon entering it with
+    tau == 0 (one launch in 2^24) computed 0 * inf = NaN and was 'absorbed' in cell 0. 1/M is finite now (FLT_MAX,
+    region_reciprocal): such a photon takes a null collision where it stands and goes on. The four photons below
+    draw tau == 0 at launch."""
     scene = gas_free_scene(rt.scenes)
     kw = dict(supergrid=(2, 2, 1), levels=3, merge_tau=2.0)
     osl = O.oracle_slabs(scene, **kw)
-    assert osl.gslab == osl.nslab - 1 and int(osl.lvl_array.max()) >= 1            # launched into merged regions
+    assert osl.gslab == osl.nslab - 1 and int(osl.box_array.max()) >= 1            # launched into boxes of several supervoxels
     assert np.isfinite(osl.maj_array).all() and float(osl.maj_array[..., 1].max()) == np.finfo(np.float32).max
     ol = O.lib()
     for pid in ZERO_TAU_PIDS:
@@ -493,7 +509,7 @@ def test_errors_are_reported_not_fatal(rt):
         tr.set_option("no_such_option", 1)
     with pytest.raises(rt.RtError):
         tr.set_scene(zenith_deg=95.0)
-    for name, bad in (("levels", 8), ("tally_match", 17), ("tally_match", -2), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
+    for name, bad in (("levels", 6), ("tally_match", 17), ("tally_match", -2), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
                       ("pool", 100), ("launch_log2k", 21), ("th_launch", 0), ("supergrid_x", -2), ("pool_waves_per_cu", 0)):
         with pytest.raises(rt.RtError, match=name):
             tr.set_option(name, bad)
