@@ -129,15 +129,15 @@ int rt_set_scene(rt_context* ctx, float zenith_rad, float azimuth_rad, float alb
  *                    jtot = 1 and azimuth = 0 the library is the 2D tracer (drivers/raytracer_gpu)
  *   "supergrid_x|y|z" supervoxel size in cells of the majorant grid laid over the cloud slab
  *                    (0 = slab majorants only, the reference's scheme; default -1 = automatic: the whole number of
- *                    cells nearest to 80 m x 80 m x 50 m, with merged regions, when the launch is stratified or sorted
+ *                    cells nearest to 50 m x 50 m x 50 m, with a box per supervoxel, when the launch is stratified or sorted
  *                    or the grid fits the Infinity Cache, else 8, 8, 4 unmerged)
  *   "levels"         every supervoxel gets a box of its own -- the supervoxels around it, up to 2^levels per axis, that
  *                    a photon standing in it crosses as one majorant region (cubes where the field is homogeneous all
  *                    around, tall columns of clear air between clouds, flat layers under them; boxes of neighbours
  *                    overlap) -- grown a layer at a time for as long as (majorant - mean extinction) * 6 V / S of the
  *                    box <= "merge_tau_milli" / 1000 -- the optical depth of null collisions a crossing photon would
- *                    meet (levels = 0: one region per supervoxel; 0..5; defaults -1 = automatic, 5 or 0 as for the
- *                    supervoxel size, and 1000)
+ *                    meet (levels = 0: one region per supervoxel; 0..6, an extent at most 31 to either side; defaults -1 = automatic, 5 or 0 as for the
+ *                    supervoxel size, and 750)
  *   "th_event", "th_scatter", "low_traverse"  lanes of a wave that must wait for the event /
  *                    scatter stage before it runs, and the number of traversing lanes below which
  *                    waiting lanes are served regardless (scheduling only: results do not change; they steer the

@@ -313,6 +313,7 @@ static void build_boxes(int nci, int ncj, int nck, int max_extent, const float* 
     {
         const int ci = (int)(e % nci), cj = (int)((e / nci) % ncj), ck = (int)(e / ((long long)nci * ncj));
         int b[6] = {ci, ci + 1, cj, cj + 1, ck, ck + 1};
+        const int c3[3] = {ci, cj, ck};
         float m = m0[e];
         double sum = ksum[e];
         long long cnt = kcnt[e];
@@ -321,7 +322,7 @@ static void build_boxes(int nci, int ncj, int nck, int max_extent, const float* 
         {
             const int ax = dir >> 1, plus = dir & 1;
             int ok = plus ? b[2 * ax + 1] < dims[ax] : b[2 * ax] > 0;
-            ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent;
+            ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent && (plus ? b[2 * ax + 1] - 1 - c3[ax] : c3[ax] - b[2 * ax]) < 31;   /* 5-bit extents */
             if (ok)
             {
                 int l[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};        /* the new layer */

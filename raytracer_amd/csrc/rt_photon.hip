@@ -1599,6 +1599,7 @@ rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum
     int b[6];
     b[0] = (int)(e % (uint32_t)nci); b[2] = (int)((e / (uint32_t)nci) % (uint32_t)ncj); b[4] = (int)(e / ((uint32_t)nci * (uint32_t)ncj));
     const int ci = b[0], cj = b[2], ck = b[4];
+    const int c3[3] = {ci, cj, ck};
     b[1] = b[0] + 1; b[3] = b[2] + 1; b[5] = b[4] + 1;
     float m = maj0[e].x;
     double sum = ksum[e];
@@ -1609,7 +1610,7 @@ rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum
         const int ax = dir >> 1;
         const bool plus = dir & 1;
         bool ok = plus ? b[2 * ax + 1] < dims[ax] : b[2 * ax] > 0;
-        ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent;
+        ok = ok && b[2 * ax + 1] - b[2 * ax] < max_extent && (plus ? b[2 * ax + 1] - 1 - c3[ax] : c3[ax] - b[2 * ax]) < 31;   /* 5-bit extents */
         if (ok)
         {
             int l[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};        // the new layer
@@ -2089,7 +2090,7 @@ struct rt_context
     float2* d_maj = nullptr;          // majorant table: supervoxels of the cloud slab, then the slabs
     int levels = -1;                  // largest region: boxes of up to 2^levels supervoxels per edge (0 = no merging,
                                       // -1 = automatic: RT_AUTO_LEVELS or 0)
-    int merge_tau_milli = 1000;       // merge criterion: (M - mean k_tot) * 6 V / S <= merge_tau_milli / 1000
+    int merge_tau_milli = 750;        // a box grows while (M - mean k_tot) * 6 V / S <= merge_tau_milli / 1000
     bool hier = false;                // any region larger than a supervoxel (selects the kernel variant)
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
@@ -2205,19 +2206,31 @@ bool wants_fine(const rt_context* c)
 int build_majorants(rt_context* c)
 {
     rt_slab_info& s = c->slabs;
-    // Automatic choices (options left at -1). Fine supervoxels with merged regions need their 9-byte-per-
-    // supervoxel tables cache-resident: the stratified launch order provides that on any grid, a grid that
-    // fits the Infinity Cache too. Uniform launch positions over a larger grid (every access a miss) do better
-    // with the coarse grid and no merging — measured on 1024x1024x128: 3.60 vs 2.28 G photons/s.
-    // The fine supervoxel is the whole number of cells nearest to 80 m x 80 m x 50 m (1..8 cells per edge):
-    // about one photon mean free path of the cumulus scenes, where the cost of crossing faces and the cost of
-    // null collisions at cloud edges balance -- 3x3x2 cells on the 25 m LES grid (C4), 2x2x2 on the 50 x 50 x 25 m
-    // grids (C3: 9.36 against 8.87 G photons/s with 3x3x2).
+    // Automatic choices (options left at -1). Fine supervoxels with boxes need their 8-byte-per-supervoxel table
+    // cache-resident: the stratified launch order provides that on any grid, a grid that fits the Infinity Cache
+    // too. Uniform launch positions over a larger grid (every access a miss) do better with the coarse grid and no
+    // boxes -- measured on 1024x1024x128: 3.60 vs 2.28 G photons/s.
+    // The fine supervoxel is the whole number of cells nearest to 50 m x 50 m x 50 m (1..8 cells per edge): with a box
+    // around every supervoxel a face costs a photon little (it is crossed once, not re-met as the boundary of an
+    // aligned partition), so the supervoxel can follow the cloud edges more closely than the 80 x 80 x 50 m that was
+    // the optimum for merged aligned regions -- 2x2x2 cells on the 25 m LES grid (C4: 29.4 against 30.7 ms with
+    // 3x3x2), 1x1x2 on the 50 x 50 x 25 m grids (C3: 19.4 against 21.3 ms with 2x2x2).
     const bool fine = wants_fine(c);
     const auto nearest = [](double target, double d) { const int n = (int)(target / d + 0.5); return n < 1 ? 1 : (n > 8 ? 8 : n); };
-    const int sgx = c->sgx >= 0 ? c->sgx : (fine ? nearest(80.0, (double)c->dx) : 8),
-              sgy = c->sgy >= 0 ? c->sgy : (fine ? nearest(80.0, (double)c->dy) : 8),
-              sgz = c->sgz >= 0 ? c->sgz : (fine ? nearest(50.0, (double)c->dz) : 4);
+    int sgx = c->sgx >= 0 ? c->sgx : (fine ? nearest(50.0, (double)c->dx) : 8),
+        sgy = c->sgy >= 0 ? c->sgy : (fine ? nearest(50.0, (double)c->dy) : 8),
+        sgz = c->sgz >= 0 ? c->sgz : (fine ? nearest(50.0, (double)c->dz) : 4);
+    // (an automatic size is coarsened until the table's indices fit: 16 bits per axis in a photon's record)
+    while (c->sgx < 0 && sgx > 0 && (c->itot + sgx - 1) / sgx > 32767) sgx *= 2;
+    while (c->sgy < 0 && sgy > 0 && (c->jtot + sgy - 1) / sgy > 32767) sgy *= 2;
+    if (s.k_lo >= 0 && sgx > 0 && sgy > 0 && sgz > 0)
+        while ((c->sgx < 0 || c->sgy < 0) &&
+               (unsigned long long)((c->itot + sgx - 1) / sgx) * (unsigned long long)((c->jtot + sgy - 1) / sgy) *
+                   (unsigned long long)((s.k_hi + 1 - s.k_lo + sgz - 1) / sgz) >= (1ull << 31))
+        {
+            if (c->sgx < 0) sgx *= 2;
+            if (c->sgy < 0) sgy *= 2;
+        }
     const int levels = c->levels >= 0 ? c->levels : (fine ? RT_AUTO_LEVELS : 0);
     c->built_fine = fine;
     const int g = (s.k_lo >= 0 && sgx > 0 && sgy > 0 && sgz > 0) ? (s.k_lo > 0 ? 1 : 0) : -1;
@@ -3163,7 +3176,7 @@ int rt_set_option(rt_context* c, const char* name, long long value)
     }
     else if (!strcmp(name, "levels"))
     {
-        if (value < -1 || value > 5) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,5]", value);
+        if (value < -1 || value > 6) return fail(RT_ERR_ARG, "rt_set_option: levels %lld outside [-1,6]", value);
         c->levels = (int)value;
         c->maj_dirty = true;
     }

@@ -99,7 +99,7 @@ DEFAULT_SUPERGRID = "auto"        # must equal the product's default (rt_set_opt
 
 
 DEFAULT_LEVELS = "auto"      # the library's defaults of options "levels" and "merge_tau_milli"
-DEFAULT_MERGE_TAU = 1.0
+DEFAULT_MERGE_TAU = 0.75
 
 
 def resolve_auto(scene, supergrid, levels, launch_log2k, pool=128, launch_sort=-1):
@@ -111,7 +111,12 @@ def resolve_auto(scene, supergrid, levels, launch_log2k, pool=128, launch_sort=-
     def nearest(target, d):       # whole number of cells nearest to the target length, 1..8
         return min(max(int(target / float(d) + 0.5), 1), 8)
     if isinstance(supergrid, str):
-        supergrid = (nearest(80.0, scene.dx), nearest(80.0, scene.dy), nearest(50.0, scene.dz)) if fine else (8, 8, 4)
+        sx, sy, sz = (nearest(50.0, scene.dx), nearest(50.0, scene.dy), nearest(50.0, scene.dz)) if fine else (8, 8, 4)
+        while -(-scene.itot // sx) > 32767:      # (the library coarsens an automatic size until its indices fit)
+            sx *= 2
+        while -(-scene.jtot // sy) > 32767:
+            sy *= 2
+        supergrid = (sx, sy, sz)
     if isinstance(levels, str):
         levels = 5 if fine else 0
     return supergrid, levels

@@ -509,7 +509,7 @@ def test_errors_are_reported_not_fatal(rt):
         tr.set_option("no_such_option", 1)
     with pytest.raises(rt.RtError):
         tr.set_scene(zenith_deg=95.0)
-    for name, bad in (("levels", 6), ("tally_match", 17), ("tally_match", -2), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
+    for name, bad in (("levels", 7), ("tally_match", 17), ("tally_match", -2), ("levels", -2), ("launch_log2k", -3), ("launch_sobol", 2), ("merge_tau_milli", -1), ("chunk", 100), ("chunk", 32),
                       ("pool", 100), ("launch_log2k", 21), ("th_launch", 0), ("supergrid_x", -2), ("pool_waves_per_cu", 0)):
         with pytest.raises(rt.RtError, match=name):
             tr.set_option(name, bad)
