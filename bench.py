@@ -596,13 +596,21 @@ def main():
                         atomics = p.get("atomics_per_photon", 0.0) * n_per_gpu
                         g_peak = ceiling_for(16 * scene.ncell, GATHER_PEAK_BY_FOOTPRINT)
                         a_peak = ceiling_for(8 * tr.nwords, ATOMIC_PEAK_BY_FOOTPRINT)
+                        # Each of the two request streams alone needs its count / its measured rate: the LARGER of the two
+                        # times is a true lower bound on the kernel's time (frac <= 1 by construction). Round 2 added the two
+                        # times (no overlap at all), which the measurements refute: C3 runs 10 % FASTER than that sum allows
+                        # (reads and atomics overlap in the memory system) -- kept as frac_additive for comparison only.
+                        t_reads, t_atomics = misses / g_peak * 1e-9, atomics / a_peak * 1e-9
                         out["gather_roofline"] = {
-                            "bound": "random 64-byte sector reads and 64-bit atomics (ceilings measured for this footprint, G/s)",
+                            "bound": "random 64-byte sector reads and 64-bit atomics (ceilings measured for this footprint, G/s); "
+                                     "frac = the slower of the two streams alone / kernel time",
                             "sector_reads_per_photon": p["fabric_reads_per_photon"],
                             "atomics_per_photon": p.get("atomics_per_photon"),
                             "peak_sector_reads_G_per_s": g_peak, "peak_atomics_G_per_s": a_peak,
                             "footprint_bytes": {"cells": 16 * scene.ncell, "tallies": 8 * tr.nwords},
-                            "frac": (misses / g_peak + atomics / a_peak) * 1e-9 / kt}
+                            "binding_stream": "atomics" if t_atomics > t_reads else "sector reads",
+                            "frac": max(t_reads, t_atomics) / kt,
+                            "frac_additive": (t_reads + t_atomics) / kt}
                     if p.get("valu_wave_insts_per_photon") is not None:
                         valu_achieved = p["valu_wave_insts_per_photon"] * n_per_gpu / kt / 1e9
                         out["valu_roofline"] = {
@@ -611,6 +619,16 @@ def main():
                             "peak_G_wave_insts_per_s": VALU_PEAK_GWAVEINST,
                             "sustained_by_microbenchmark_G_wave_insts_per_s": 1040.0,   # v_xor_b32, 8 waves/SIMD
                             "frac": valu_achieved / VALU_PEAK_GWAVEINST}
+                        if p.get("valu_issue_cycles_per_photon") is not None:
+                            # not every instruction is a 2-cycle one: Philox's 64-bit multiply-adds hold the SIMD 4 cycles,
+                            # reciprocals and square roots 8 (tools/valu_rate.hip); with the instruction mix the counters
+                            # give, the share of the SIMDs' cycles that issue this kernel's VALU work
+                            cyc = p["valu_issue_cycles_per_photon"] * n_per_gpu / kt
+                            out["valu_roofline"].update({
+                                "issue_cycles_per_photon": p["valu_issue_cycles_per_photon"],
+                                "int64_insts_per_photon": p.get("valu_int64_insts_per_photon"),
+                                "trans_insts_per_photon": p.get("valu_trans_insts_per_photon"),
+                                "frac_issue_cycles": cyc / (1024 * 2.4e9)})
                         # roofline.achieved = max(bytes / BW_peak, valu / VALU_peak), `bound` names
                         # the binding ceiling. The streaming-HBM figure (measured live) stays in roofline.hbm; the VALU
                         # instruction count per photon is the replayed counter, the kernel time is this run's.
@@ -624,10 +642,11 @@ def main():
                         # the microbenchmarks over the same footprint (64-byte sector reads + 64-bit atomics, additive)
                         g = out.get("gather_roofline")
                         if g and g["frac"] > out["roofline"]["frac"]:
-                            acc = (g["sector_reads_per_photon"] + (g["atomics_per_photon"] or 0.0)) * n_per_gpu / kt / 1e9
+                            per_photon = (g["atomics_per_photon"] or 0.0) if g["binding_stream"] == "atomics" else g["sector_reads_per_photon"]
+                            acc = per_photon * n_per_gpu / kt / 1e9
                             out["roofline"].update({"bound": "gather", "achieved": acc, "peak": acc / g["frac"],
-                                                    "unit": "G random accesses/s (64-byte sector reads + 64-bit atomics at the "
-                                                            "rates measured for this footprint, additive)",
+                                                    "unit": "G random accesses/s of the binding stream (" + g["binding_stream"] + "; rate "
+                                                            "measured by tools/gather_rate.hip for this footprint)",
                                                     "frac": g["frac"]})
             except Exception:
                 pass

@@ -36,6 +36,14 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_INSTS_VALU" in pmc:
     pmc["active_lanes_per_valu_inst"] = pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"]
     pmc["valu_wave_insts_per_photon"] = pmc["SQ_INSTS_VALU"] / photons
+if "SQ_INSTS_VALU_TRANS_F32" in pmc and "SQ_INSTS_VALU_INT64" in pmc and "SQ_INSTS_VALU" in pmc:
+    # issue cycles of the VALU work as tools/valu_rate.hip measures them (profiles/r1_microbench_valu_rate.txt): a wave64
+    # instruction holds its SIMD 2 cycles, a 64-bit integer one (Philox's v_mad_u64_u32) 4, a transcendental (v_rcp_f32,
+    # v_sqrt_f32) 8
+    trans, i64 = pmc["SQ_INSTS_VALU_TRANS_F32"], pmc["SQ_INSTS_VALU_INT64"]
+    pmc["valu_trans_insts_per_photon"] = trans / photons
+    pmc["valu_int64_insts_per_photon"] = i64 / photons
+    pmc["valu_issue_cycles_per_photon"] = (2.0 * (pmc["SQ_INSTS_VALU"] - trans - i64) + 4.0 * i64 + 8.0 * trans) / photons
 pmc["launch_log2k"] = launch_log2k
 pmc["launch_tile_log2"] = int(sys.argv[5]) if len(sys.argv) > 5 else 0     # bench.py --launch-tile-log2 of the profiled run
 if "FETCH_SIZE" in pmc:
@@ -49,7 +57,7 @@ if "SQ_INSTS_LDS" in pmc and "SQ_LDS_BANK_CONFLICT" in pmc:
     pmc["lds_conflict_cycles_per_lds_inst"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_INSTS_LDS"]
 json.dump(pmc, open(f"{here}/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
 keys = ("photons_per_launch", "launch_log2k", "launch_tile_log2", "hbm_bytes_per_launch", "fabric_reads_per_photon", "atomics_per_photon",
-        "valu_wave_insts_per_photon", "active_lanes_per_valu_inst", "salu_insts_per_photon", "lds_insts_per_photon",
+        "valu_wave_insts_per_photon", "valu_issue_cycles_per_photon", "valu_trans_insts_per_photon", "valu_int64_insts_per_photon", "active_lanes_per_valu_inst", "salu_insts_per_photon", "lds_insts_per_photon",
         "lds_conflict_cycles_per_lds_inst", "kernel_avg_ns")
 json.dump(dict({k: pmc.get(k) for k in keys}, source=f"profiles/{tag}_pmc.json"),
           open(f"{here}/pmc_{workload}.json", "w"), indent=1)

@@ -55,6 +55,25 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{c0, c1, c2, c3};
 }
 
+// The same block with the ten round keys handed in, {k0 + r * 0x9E3779B9, k1 + r * 0xBB67AE85} for r = 0 .. 9 (the host
+// computes them once per launch: they depend on the seed alone).
+__device__ __forceinline__ u32x4 philox4x32_10_keys(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const uint32_t (&rk)[20])
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round)
+    {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, rk[2 * round], 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, rk[2 * round + 1], 0x96);
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
 // top 24 bits -> [0,1) on the 2^-24 lattice (exact)
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 

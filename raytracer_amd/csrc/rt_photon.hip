@@ -174,6 +174,10 @@ struct PoolArgs
     int tally_match;              // RT_SLAB_TALLY: rounds of matching equal tally words across the wave (0: runs of neighbours only)
     float xs, ys, inv_dx, inv_dy, inv_dz;
     float hx, hy, hz, inv_hx, inv_hy, inv_hz, zc0, zc1;
+    // Philox's ten round keys of this launch's seed, {k0 + r * 0x9E3779B9, k1 + r * 0xBB67AE85}: the event stage reads
+    // them with its other arguments (scalar loads through the kernarg pointer) instead of deriving them round by round
+    // -- twenty scalar additions per event round on a CU whose one scalar unit is as loaded as its vector units
+    uint32_t round_keys[20];
 };
 
 // Read-only while the tracer runs (the cursors sit elsewhere: a line that takes atomics must not also serve
@@ -782,6 +786,10 @@ constexpr int kTallyMatchMin = 3;
 #ifndef RT_T_STEPS
 #define RT_T_STEPS 2
 #endif
+// the event stage takes Philox's round keys from the kernel arguments (1) or derives them from the seed each round (0)
+#ifndef RT_ROUND_KEYS
+#define RT_ROUND_KEYS 1
+#endif
 constexpr int kPoolBlock = 64;
 
 // One traverse step of the pool kernel INSIDE THE GRIDDED SLAB on the photon held in the lane's locals (x, y,
@@ -1192,6 +1200,14 @@ rt_trace_pool_kernel(const PoolArgs a)
             // the pool's photons wait for two frequent stages instead of three, so rounds are fuller.
             if (active)
             {
+#if RT_ROUND_KEYS
+                // asked for here, with the stage's other scalar loads and ahead of the record's LDS reads: issued where
+                // Philox starts, their latency would sit in front of it
+                uint32_t rk[20];
+#pragma unroll
+                for (int r = 0; r < 20; ++r)
+                    rk[r] = k->round_keys[r];
+#endif
                 uint32_t cell = 0;
                 float inv_m = 0.0f;
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1233,9 +1249,13 @@ rt_trace_pool_kernel(const PoolArgs a)
                 // the ten round keys are wave-uniform and loop-invariant: left alone the compiler hoists all
                 // twenty out of the wave's loop, spills them to VGPR lanes and reads them back with twenty
                 // v_readlane per round; redefining the key here keeps the schedule on the scalar unit
+#if RT_ROUND_KEYS
+                const u32x4 w = philox4x32_10_keys(pid_lo, pid_hi, nev, 0u, rk);
+#else
                 uint32_t rk0 = key0, rk1 = key1;
                 asm volatile("" : "+s"(rk0), "+s"(rk1));
                 const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, rk0, rk1);
+#endif
                 ++nev;
                 out_hn = pid_hi | (nev << 8);
                 float tau_new = free_path_tau(u01(w.y));
@@ -2712,6 +2732,11 @@ int trace_impl(rt_context* c, uint64_t seed, uint64_t pid_begin, uint64_t count,
         a.cells = c->d_cells; a.maj = c->d_maj; a.tallies = c->d_tallies;
         a.cold = d_cold; a.cursor = cursor;
         a.seed = seed;
+        for (int r = 0; r < 10; ++r)
+        {
+            a.round_keys[2 * r] = (uint32_t)seed + (uint32_t)r * 0x9E3779B9u;
+            a.round_keys[2 * r + 1] = (uint32_t)(seed >> 32) + (uint32_t)r * 0xBB67AE85u;
+        }
         a.itot = c->itot; a.jtot = c->jtot; a.ktot = c->ktot; a.ncol = (uint32_t)c->ncol;
         a.nbi = c->nbi; a.nbij = c->nbij;
         a.gslab = sl.gslab; a.nci = sl.nci; a.ncj = sl.ncj; a.nck = sl.nck;

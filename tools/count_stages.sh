@@ -19,7 +19,7 @@ s=mark(s,"        ++round_ctr;","SELECT_BEGIN",after=False)
 open('/tmp/isa/mark.hip','w').write(s)
 PY
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -DRT_ONLY_DEFAULT_POOL "$@" -S --cuda-device-only mark.hip -o mark.s 2>&1 | grep error
-awk '/^_ZN12_GLOBAL__N_120rt_trace_pool_kernelILi0ELb0ELi128ELb1EEEvNS_8PoolArgsE:/{p=1} p{print} /\.end_amdhsa_kernel/{if(p){exit}}' mark.s > main_mark.s
+awk '/^_ZN12_GLOBAL__N_120rt_trace_pool_kernelILi0ELb0ELi128ELb1ELb0EEEvNS_8PoolArgsE:/{p=1} p{print} /\.end_amdhsa_kernel/{if(p){exit}}' mark.s > main_mark.s
 python3 - <<'PY'
 lines=open('/tmp/isa/main_mark.s').read().splitlines()
 marks=[(i,l.split('MARK_')[1]) for i,l in enumerate(lines) if 'MARK_' in l]

@@ -22,7 +22,7 @@ def run(opts, rounds=3):
         tr.reset(); tr.trace(1, r * n, n); tr.synchronize(); ts.append(tr.last_trace_ms())
     return statistics.median(ts)
 
-base = dict(pool=128, chunk=256, levels=-1, merge_tau_milli=1000, launch_log2k=8, launch_tile_log2=5, th_launch=40, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=-1, supergrid_y=-1, supergrid_z=-1)
+base = dict(pool=128, chunk=256, levels=-1, merge_tau_milli=750, launch_log2k=8, launch_tile_log2=5, th_launch=40, pool_waves_per_cu=32, th_event=20, th_scatter=16, low_traverse=20, blocks_per_cu=6, supergrid_x=-1, supergrid_y=-1, supergrid_z=-1)
 for kv in os.environ.get("RT_TUNE_OPTS", "").split(","):      # e.g. RT_TUNE_OPTS=launch_log2k=3,chunk=512
     if "=" in kv:
         base[kv.split("=")[0]] = int(kv.split("=")[1])
