@@ -70,7 +70,7 @@ def ceiling_for(footprint_bytes, table):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --workload c5: 6 = one sweep of the zenith angles)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --workload c5: 12 = two sweeps of the six zenith angles)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--photons-log2", type=int, default=None, help="photons per GPU per step (log2)")
@@ -235,7 +235,8 @@ def sweep_bench(args, rt, torch):
     """--workload c5 (one GPU): runs of 2^26 photons under six solar zenith angles with the grids resident, each run
     followed by what raytracer_3d_io.cu:174-212 does after its kernel -- seven device-to-host copies and seven files.
     Pipelined as the driver raytracer_3d_io_gpu does it: the copy of run k leaves one tally buffer over the library's
-    copy stream into pinned memory while run k+1 is traced into the other, and a host thread writes the files. A
+    copy stream into pinned memory while run k+1 is traced into the other, and host threads write the files of up to
+    four runs side by side (a run's files take four times as long as its trace and download). A
     step is one run; the timed region ends when the last file is closed. Measured beside it: the same runs strictly one
     after another (the reference's order), the trace alone, and the same sweep on the C3 grid."""
     import tempfile
@@ -247,11 +248,16 @@ def sweep_bench(args, rt, torch):
         k, tile = rt.choose_launch_order(scene.itot, scene.jtot, scene.ktot, n)
         tr.set_option("launch_log2k", k); tr.set_option("launch_tile_log2", tile)
         tr.prepare()
-        sets = [tr.pinned_tallies() for _ in range(2)]
-        dirs = [os.path.join(outdir, f"run_{i:02d}") for i in range(2)]
+        # a ring of host sets: the files of a run (26 ms of write() for 264 MB on two threads) take four times as long as
+        # its trace and download, so the writers of up to `depth` runs work side by side -- each on its own set of
+        # pinned arrays and its own directory -- while the device alternates between its two tally buffers
+        depth = max(2, int(os.environ.get("RT_C5_WRITERS", "4")))
+        sets = [tr.pinned_tallies() for _ in range(depth)]
+        dirs = [os.path.join(outdir, f"run_{i:02d}") for i in range(depth)]
         for d in dirs:
             os.makedirs(d, exist_ok=True)
         state = {"bytes": 0, "write_s": 0.0, "err": None}
+        state_lock = threading.Lock()
 
         def write(ticket, arrays, d):
             try:
@@ -259,33 +265,35 @@ def sweep_bench(args, rt, torch):
                     tr.tallies_wait(ticket)
                 t0 = time.perf_counter()
                 rt.save_tallies(arrays, d)
-                state["write_s"] += time.perf_counter() - t0
-                state["bytes"] += sum(a.nbytes for a in arrays.values())
+                with state_lock:
+                    state["write_s"] += time.perf_counter() - t0
+                    state["bytes"] += sum(a.nbytes for a in arrays.values())
             except Exception as exc:      # noqa: BLE001
                 state["err"] = exc
 
         def sweep(jobs, first_job, pipelined):
-            writer = None
+            writers = [None] * depth
             for j in range(jobs):
                 job = first_job + j
                 zen = C5_ZENITHS[job % len(C5_ZENITHS)]
                 tr.set_scene(zen, scene.azimuth_deg, scene.albedo)
                 tr.reset()
                 tr.trace(args.seed, job * n, n)
-                arrays = sets[j % 2][0]
+                arrays = sets[j % depth][0]
                 if pipelined:
+                    if writers[j % depth] is not None:      # this set's files of `depth` runs ago are written
+                        writers[j % depth].join()
                     ticket = tr.tallies_async(arrays)
                     tr.swap_tally_buffer()
-                    if writer is not None:
-                        writer.join()
-                    writer = threading.Thread(target=write, args=(ticket, arrays, dirs[j % 2]))
-                    writer.start()
+                    writers[j % depth] = threading.Thread(target=write, args=(ticket, arrays, dirs[j % depth]))
+                    writers[j % depth].start()
                 else:
                     tr.synchronize()
                     got = tr.tallies()          # seven blocking copies into pageable memory, as copy_from_gpu does
-                    write(None, got, dirs[j % 2])
-            if writer is not None:
-                writer.join()
+                    write(None, got, dirs[j % depth])
+            for w in writers:
+                if w is not None:
+                    w.join()
             tr.synchronize()
             if state["err"] is not None:
                 raise state["err"]
@@ -308,7 +316,7 @@ def sweep_bench(args, rt, torch):
             kernel_ms.append(tr.last_trace_ms())
         trace_only = time.perf_counter() - t0
         # the last run's files against the device's counts: what was written is what was traced
-        t = {name: np.fromfile(os.path.join(dirs[(steps - 1) % 2], name + ".bin"), dtype=np.uint64) for name in rt.TALLY_NAMES}
+        t = {name: np.fromfile(os.path.join(dirs[(steps - 1) % depth], name + ".bin"), dtype=np.uint64) for name in rt.TALLY_NAMES}
         shaped = {name: v.reshape((scene.ktot, scene.jtot, scene.itot) if name.startswith("atmos") else (scene.jtot, scene.itot))
                   for name, v in t.items()}
         if rt.photon_balance(shaped) != 0 or int(t["toa_down"].sum()) != n:
@@ -317,7 +325,7 @@ def sweep_bench(args, rt, torch):
             tr.free_pinned(s_[1])
         tr.set_option("stats", 1); tr.reset(); tr.trace(args.seed, 0, n); tr.synchronize(); ev = tr.events(); tr.set_option("stats", 0)
         tr.close()
-        return {"grid": [scene.itot, scene.jtot, scene.ktot], "jobs": steps, "photons_per_job": n,
+        return {"grid": [scene.itot, scene.jtot, scene.ktot], "jobs": steps, "photons_per_job": n, "writers_in_flight": depth,
                 "launch_log2k": k, "output_bytes_per_job": wrote // max(steps, 1),
                 "end_to_end_photons_per_s": steps * n / piped, "jobs_per_s": steps / piped, "ms_per_job": piped / steps * 1e3,
                 "not_pipelined_photons_per_s": steps * n / serial, "not_pipelined_ms_per_job": serial / steps * 1e3,
@@ -325,7 +333,7 @@ def sweep_bench(args, rt, torch):
                 "kernel_ms": sum(kernel_ms) / len(kernel_ms), "file_write_s_per_job": write_s / steps,
                 "file_write_GB_per_s": wrote / max(write_s, 1e-9) / 1e9, "events": ev}
 
-    steps = args.steps if args.steps is not None else len(C5_ZENITHS)   # default: one sweep of the six angles
+    steps = args.steps if args.steps is not None else 2 * len(C5_ZENITHS)   # default: two sweeps of the six angles (the writers of four runs are in flight: one sweep is mostly the pipeline filling and draining)
     warmup = max(args.warmup, 1)
     with tempfile.TemporaryDirectory(dir=args.outdir) as d:
         io_scene = rt.scenes.cumulus(240, 240, 284, 100.0, 100.0, 30.0, n_clouds=60, seed=7, z_base=900.0, z_top=3000.0,

@@ -10,6 +10,7 @@
 #include "../include/rt_photon.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -18,6 +19,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -56,10 +58,14 @@ struct Config
     // reference prepares for by copying its tally arrays to the device, raytracer_3d.cu:89, 98-104)
     bool resume = false;
     bool input_f64 = false;                   // sidecar says the data files hold float64
-    // --pipeline=1 (default) | 0: a sweep traces job k+1 while job k's seven arrays come down over a copy stream into
-    // pinned memory and a host thread writes its files (rt_download_tallies_async, rt_swap_tally_buffer); 0 = the
+    // --pipeline=1 (default) | 0 | K: a sweep traces job k+1 while job k's seven arrays come down over a copy stream into
+    // pinned memory and host threads write its files (rt_download_tallies_async, rt_swap_tally_buffer); 0 = the
     // reference's order, one thing after another (raytracer_3d_io.cu:156-212). The files are the same bytes either way.
+    // K >= 2: the files of up to K jobs are written side by side, each job from its own set of pinned arrays (a job's
+    // files take several times as long as its trace and download); 1 = automatic: 4, fewer where four sets would
+    // page-lock more than 4 GiB, never fewer than 2.
     bool pipeline = true;
+    int pipeline_depth = 0;
 };
 
 inline void die(const std::string& msg)
@@ -170,7 +176,12 @@ inline void parse_args(int argc, char** argv, Config& c)
                 if (c.azimuth_deg.empty()) die("--azimuth needs at least one angle");
             }
             else if (key == "resume") c.resume = (val != "0");
-            else if (key == "pipeline") c.pipeline = (val != "0");
+            else if (key == "pipeline")
+            {
+                c.pipeline = (val != "0");
+                c.pipeline_depth = std::stoi(val) >= 2 ? std::stoi(val) : 0;
+                if (c.pipeline_depth > 16) die("--pipeline: at most 16 jobs in flight");
+            }
             else if (key == "seed") c.seed = std::stoull(val);
             else if (key == "ngpus") c.ngpus = std::stoi(val);
             else if (key == "indir") c.indir = val;
@@ -414,9 +425,15 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     // Host side of the results: two sets of the seven arrays in pinned memory (the copy engine writes them while the
     // GPU traces the next job) -- one set when the pipeline is off.
     const size_t nwords = 5 * ncol + 2 * ncell;
-    const int nsets = c.pipeline && jobs.size() > 1 ? 2 : 1;
-    uint64_t* pinned[2] = {nullptr, nullptr};
-    uint64_t* ptrs[2][RT_N_TALLIES];
+    int depth = c.pipeline_depth;
+    if (depth == 0)
+    {
+        depth = 4;
+        while (depth > 2 && (size_t)depth * nwords * sizeof(uint64_t) > ((size_t)4 << 30)) --depth;
+    }
+    const int nsets = c.pipeline && jobs.size() > 1 ? std::min<int>(depth, (int)jobs.size()) : 1;
+    std::vector<uint64_t*> pinned(nsets, nullptr);
+    std::vector<std::array<uint64_t*, RT_N_TALLIES>> ptrs(nsets);
     for (int b = 0; b < nsets; ++b)
     {
         void* p = nullptr;
@@ -430,6 +447,9 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     // What is left of a job once its counts are on the host: files, checkpoint, the reference's stdout lines.
     struct Done { size_t job; int set; uint64_t first_id; double seconds; };
     std::string writer_error;
+    std::mutex writer_mutex;
+    const auto set_writer_error = [&](const std::string& what) { std::lock_guard<std::mutex> g(writer_mutex); if (writer_error.empty()) writer_error = what; };
+    const auto get_writer_error = [&] { std::lock_guard<std::mutex> g(writer_mutex); return writer_error; };
     const auto finish = [&](const Done& d)
     {
         const Job& job = jobs[d.job];
@@ -455,10 +475,11 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
             k.zenith_deg = job.zen; k.azimuth_deg = job.azi; k.albedo = c.albedo; k.fixed_dot = c.fixed_dot;
             write_checkpoint(job.dir, k);
         }
-        catch (const std::exception& e) { writer_error = e.what(); }
+        catch (const std::exception& e) { set_writer_error(e.what()); }
     };
 
-    std::thread writer;
+    std::vector<std::thread> writers(nsets);       // writers[s]: the thread that writes the files held in set s
+    const auto join_writers = [&] { for (std::thread& w : writers) if (w.joinable()) w.join(); };
     bool warned_host_sum = false;
     double trace_seconds = 0.;
     const auto sweep0 = std::chrono::high_resolution_clock::now();
@@ -518,8 +539,8 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
             trace_seconds += dur;
             std::cout << "Duration: " << std::setprecision(5) << dur << " (s)" << std::endl;  // raytracer_3d.cu:169
             std::cout << "Photons per second: " << std::setprecision(6) << (double)n_photons / dur << std::endl;
-            if (writer.joinable()) writer.join();
-            check(rt_download_tallies(ctx[0], ptrs[set]), "rt_download_tallies");
+            join_writers();
+            check(rt_download_tallies(ctx[0], ptrs[set].data()), "rt_download_tallies");
             if (host_sum)
             {
                 std::vector<uint64_t> other(nwords);
@@ -539,25 +560,26 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
         {
             // pipelined sweep: the copy of this job starts when its trace ends (an event, not a host wait), the context
             // moves on to its other tally buffer, and the host goes straight on to enqueue the next job; a thread waits
-            // for the copy and writes the files. The set of host arrays is free again: its writer was joined two jobs ago.
+            // for the copy and writes the files. The set of host arrays must be free again: the files of the job that
+            // used it, nsets jobs ago, are waited for first (the writers of the jobs in between go on side by side).
+            if (writers[set].joinable()) writers[set].join();
             int ticket = 0;
-            check(rt_download_tallies_async(ctx[0], ptrs[set], &ticket), "rt_download_tallies_async");
+            check(rt_download_tallies_async(ctx[0], ptrs[set].data(), &ticket), "rt_download_tallies_async");
             check(rt_swap_tally_buffer(ctx[0]), "rt_swap_tally_buffer");
-            if (writer.joinable()) writer.join();
             if (sweep_z || sweep_a) std::cout << "Writing " << job.dir << std::endl;
-            writer = std::thread([&, jn, set, first_id, ticket, s0]
+            writers[set] = std::thread([&, jn, set, first_id, ticket, s0]
             {
-                if (rt_download_wait(ctx[0], ticket) != RT_OK) { writer_error = rt_last_error(); return; }
+                if (rt_download_wait(ctx[0], ticket) != RT_OK) { set_writer_error(rt_last_error()); return; }
                 finish(Done{jn, set, first_id, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - s0).count()});
             });
         }
-        if (!writer_error.empty()) break;
+        if (!get_writer_error().empty()) break;
     }
-    if (writer.joinable()) writer.join();
+    join_writers();
     if (!writer_error.empty()) die(writer_error);
     for (int g = 0; g < c.ngpus; ++g) check(rt_synchronize(ctx[g]), "rt_synchronize");
     const double sweep_s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - sweep0).count();
-    if (nsets == 2)
+    if (nsets >= 2)
     {
         // one line per sweep in place of one per job (a job's end is not waited for on the host)
         std::cout << "Duration: " << std::setprecision(5) << sweep_s << " (s)" << std::endl;
@@ -567,7 +589,7 @@ inline void run(const Config& c, const std::vector<float>& k_gas, const std::vec
     std::cout << "{\"photons_per_job\": " << n_photons << ", \"jobs\": " << jobs.size() << ", \"gpus\": " << c.ngpus
               << ", \"grid\": [" << c.itot << ", " << c.jtot << ", " << c.ktot << "], \"launch_log2k\": " << launch_log2k
               << ", \"launch_tile_log2\": " << launch_tile_log2 << ", \"seed\": " << c.seed
-              << ", \"pipeline\": " << (nsets == 2 ? "true" : "false") << std::setprecision(9)
+              << ", \"pipeline\": " << (nsets >= 2 ? "true" : "false") << ", \"jobs_in_flight\": " << nsets << std::setprecision(9)
               << ", \"sweep_seconds\": " << sweep_s << ", \"end_to_end_photons_per_s\": "
               << (double)n_photons * (double)jobs.size() / sweep_s;
     if (nsets == 1) std::cout << ", \"trace_seconds\": " << trace_seconds;

@@ -267,7 +267,7 @@ def test_pipelined_sweep_writes_the_same_bytes_and_a_json_summary(tmp_path):
     sc = scenes.cumulus(48, 40, 30, 100.0, 100.0, 30.0, n_clouds=8, seed=9, z_base=240.0, z_top=600.0, name="sweep")
     zens = (0, 15, 30, 45, 60, 75)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "2", "3"):       # 1: four jobs' files in flight (automatic), 2 / 3: that many, 0: the reference's order
         d = tmp_path / f"pipe{mode}"
         d.mkdir()
         sc.write(str(d))
@@ -275,15 +275,17 @@ def test_pipelined_sweep_writes_the_same_bytes_and_a_json_summary(tmp_path):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         summary = json.loads(r.stdout.splitlines()[-1])
-        assert summary["jobs"] == 6 and summary["photons_per_job"] == 1 << 17 and summary["pipeline"] == (mode == "1")
+        assert summary["jobs"] == 6 and summary["photons_per_job"] == 1 << 17 and summary["pipeline"] == (mode != "0")
+        assert summary["jobs_in_flight"] == {"1": 4, "0": 1, "2": 2, "3": 3}[mode]
         assert summary["grid"] == [48, 40, 30] and summary["end_to_end_photons_per_s"] > 0
-        assert sum(l.startswith("Duration: ") for l in r.stdout.splitlines()) == (1 if mode == "1" else 6)
+        assert sum(l.startswith("Duration: ") for l in r.stdout.splitlines()) == (1 if mode != "0" else 6)
         out[mode] = d
     for zen in zens:
         sub = f"zenith_{zen:02d}"
         for name in list(TALLY_NAMES) + ["checkpoint"]:
             fn = name + ".bin" if name != "checkpoint" else name
-            assert open(out["1"] / sub / fn, "rb").read() == open(out["0"] / sub / fn, "rb").read(), (zen, name)
+            for mode in ("1", "2", "3"):
+                assert open(out[mode] / sub / fn, "rb").read() == open(out["0"] / sub / fn, "rb").read(), (mode, zen, name)
         sc.zenith_deg = float(zen)
         k, _ = __import__("raytracer_amd").choose_launch_order(sc.itot, sc.jtot, sc.ktot, 1 << 17)
         want, _ = O.photon_oracle(sc, 12, 0, 1 << 17, launch_log2k=k)
