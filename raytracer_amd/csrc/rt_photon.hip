@@ -846,8 +846,10 @@ constexpr int kPoolBlock = 64;
                         /* (the motion is monotone on each axis; a coordinate that sits on a face may round to either */ \
                         /* side, and the box of the supervoxel behind the face reaches back over it); for a box of one */ \
                         /* supervoxel the clamp returns the index itself */ \
-                        ci = min(max(cell_of(x, a.inv_hx, a.nci), px ? ci : bx0), px ? bx1 - 1 : ci); \
-                        cj = min(max(cell_of(y, a.inv_hy, a.ncj), py ? cj : by0), py ? by1 - 1 : cj); \
+                        /* (no clamp to the grid first, as cell_of would: the box lies inside it; a position that is not a */ \
+                        /* number converts to 0 and is clamped like any other) */ \
+                        ci = min(max((int)(x * a.inv_hx), px ? ci : bx0), px ? bx1 - 1 : ci); \
+                        cj = min(max((int)(y * a.inv_hy), py ? cj : by0), py ? by1 - 1 : cj); \
                         ck = min(max((int)((z - a.zc0) * a.inv_hz), up ? ck : bz0), up ? bz1 - 1 : ck); \
                     } \
                     /* a face: carry tau on, step over the face (periodic in x and y); no face: 1/M rides in tau */ \
