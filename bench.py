@@ -642,7 +642,16 @@ def main():
                         # instruction count per photon is the replayed counter, the kernel time is this run's.
                         hbm = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac")}
                         out["roofline"]["hbm"] = hbm
-                        if valu_achieved / VALU_PEAK_GWAVEINST > hbm["frac"]:
+                        if out["valu_roofline"].get("frac_issue_cycles") is not None:
+                            # with the instruction mix known, the VALU ceiling is priced in issue cycles (a 64-bit multiply-add
+                            # is not a 2-cycle instruction): SIMD cycles that issue this kernel's VALU work / all SIMD cycles
+                            cyc_g = out["valu_roofline"]["issue_cycles_per_photon"] * n_per_gpu / kt / 1e9
+                            if out["valu_roofline"]["frac_issue_cycles"] > hbm["frac"]:
+                                out["roofline"].update({"bound": "valu", "achieved": cyc_g, "peak": 1024 * 2.4,
+                                                        "unit": "G SIMD issue cycles/s (wave64 VALU instruction 2 cycles, 64-bit integer 4, "
+                                                                "transcendental 8: tools/valu_rate.hip; 1024 SIMDs x 2.4 GHz)",
+                                                        "frac": out["valu_roofline"]["frac_issue_cycles"]})
+                        elif valu_achieved / VALU_PEAK_GWAVEINST > hbm["frac"]:
                             out["roofline"].update({"bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK_GWAVEINST,
                                                     "unit": "G wave-instructions/s (wave64 VALU, 2-cycle issue x 1024 SIMDs x 2.4 GHz)",
                                                     "frac": valu_achieved / VALU_PEAK_GWAVEINST})
