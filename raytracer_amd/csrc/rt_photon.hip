@@ -117,10 +117,9 @@ struct TraceArgs
 {
     const float4* cells;      // {k_tot = gas + cloud, ssa, asy, k_cloud} per cell [k][j][i]: one 16-byte
                               // record, so a collision costs one memory sector however it ends
-    const float2* maj;        // {M, 1/M} of the region a supervoxel belongs to: ncoarse supervoxels
-                              // [ck][cj][ci], then one entry per slab. The three low mantissa bits of a
-                              // supervoxel's M hold its region level: the region is the aligned cube of 2^level
-                              // supervoxels per edge around it. 1/M is finite (FLT_MAX where M is 0)
+    const float2* maj;        // ncoarse supervoxels [ck][cj][ci]: {M of the supervoxel's own box, its six extents in
+                              // 5 bits each} (rt_boxes_kernel; the step takes 1/M from M: region_reciprocal, finite,
+                              // FLT_MAX where M is 0); then one entry {M, 1/M} per slab
     unsigned long long* tallies;  // concatenated, rt_tally order
     unsigned long long* events;   // RT_N_EVENTS counters
     uint64_t seed;
@@ -798,9 +797,9 @@ constexpr int kPoolBlock = 64;
 // IX, IY, IZ are the direction reciprocals. Used by the traverse stage and, fused, at the end of the new-
 // direction stage (a photon that has just been given a direction always traverses next: doing it in the same
 // round saves the slot selection and the LDS round trip of one round per scattering). The region is the
-// aligned cube of 2^L supervoxels per edge around (ci, cj, ck); HIER = false skips the level and the cube
-// arithmetic. Inside a merged region the supervoxel indices follow the position (kept within the region: a
-// coordinate on one of its faces may round to the neighbour's side). A photon that leaves the slab through
+// box of supervoxel (ci, cj, ck) -- its six extents ride beside M in the table entry; HIER = false (no box larger
+// than its supervoxel anywhere) skips the box arithmetic. Inside a box the supervoxel indices follow the position
+// (kept within the box and never back along an axis: a coordinate on a face may round to either side). A photon that leaves the slab through
 // its top or bottom moves its slab index and waits for the slab stage (PS_SLAB), which owns everything
 // outside the grid: the clear-air slabs, the domain top and the surface. 1/M is finite in the tables
 // (majorant_reciprocal), so tau * (1/M) is a number whatever the region holds.
@@ -1560,7 +1559,7 @@ rt_trace_pool_kernel(const PoolArgs a)
 // ------------------------------------------------------------------------------------------
 // Majorant grid of the cloud slab: per supervoxel the max of k_tot over its cells, stored as {M, 1/M}
 // (generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels), and the sum and
-// number of its cells for the merge criterion.
+// number of its cells for the growth criterion of the boxes (rt_boxes_kernel).
 __global__ void __launch_bounds__(64)
 rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, double* __restrict__ ksum,
                    int* __restrict__ kcnt, uint32_t ncoarse,
@@ -1568,7 +1567,7 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, d
                    int sx, int sy, int sz, int nci, int ncj)
 {
     // One THREAD per supervoxel, cells visited in (k, j, i) order: the double-precision sum of k_tot feeds the
-    // merge criterion of build_regions, which must decide exactly as the oracle's does, so its rounding
+    // growth criterion of rt_boxes_kernel, which must decide exactly as the oracle's does, so its rounding
     // must not depend on a reduction tree. Runs once per scene.
     const uint32_t e = blockIdx.x * 64u + threadIdx.x;
     if (e >= ncoarse)
@@ -2117,7 +2116,7 @@ struct rt_context
     size_t maj_capacity = 0, ncoarse = 0;
     bool maj_dirty = true;
     int sgx = -1, sgy = -1, sgz = -1; // supervoxel size in cells (0 = no grid, slabs only; -1 = automatic:
-                                      // 3x3x2 merged by build_regions, or 8x8x4 unmerged, see build_majorants)
+                                      // nearest to 50 x 50 x 50 m with a box each, or 8x8x4 without, see build_majorants)
     bool built_fine = false;          // what the automatic choices were made for (wants_fine below)
     int th_event = 20, th_scatter = 16, low_traverse = 20;
     int pool = RT_FAST_POOL;          // photons per wave kept in LDS by the pool kernel (0 = lane-resident kernel)
@@ -2218,7 +2217,7 @@ size_t sort_blocks(const rt_context* c) { return (size_t)RT_SORT_BLOCKS_X2 * (si
 // packed cells that fit the Infinity Cache: uniform launch positions need no help there
 bool small_grid(const rt_context* c) { return 16ull * (unsigned long long)c->ncell <= (256ull << 20); }
 
-// Fine supervoxels with merged regions need their tables cache-resident: the stratified launch order provides that
+// Fine supervoxels with a box each need their table cache-resident: the stratified launch order provides that
 // on any grid, the launch sort (pool kernel, uniform launch) too, and so does a grid that fits the Infinity Cache.
 bool wants_fine(const rt_context* c)
 {
