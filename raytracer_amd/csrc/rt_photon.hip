@@ -808,8 +808,10 @@ constexpr int kPoolBlock = 64;
                     /* the step guard (a position that is not a number, or a photon of age 31 in a tick round): the step */ \
                     /* is taken regardless -- its indices stay inside the tables whatever the position holds -- and */ \
                     /* the photon is retired after it: no else-branch around the hot code */ \
-                    const bool bad = !(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask); \
+                    /* (age holds the five top bits alone: adding a tick to age 31 wraps -- no wave-uniform tick flag to test) */ \
+                    const uint32_t age_old = age; \
                     age += age_inc; \
+                    const bool bad = !(z == z) || !(x == x) || !(y == y) || age < age_old; \
                     if (STATS) ++ev_step; \
                     const float2 mm = (MM); \
                     __builtin_amdgcn_s_setprio(0); \
@@ -955,7 +957,7 @@ constexpr int kPoolBlock = 64;
                 const int nslab_ = cb->nslab; \
                 if (slab >= 0 && slab < nslab_) \
                 { \
-                    if (__builtin_expect(!(z == z) || !(x == x) || !(y == y) || (tick && age == kAgeMask), 0)) \
+                    if (__builtin_expect(!(z == z) || !(x == x) || !(y == y) || (uint32_t)(age + age_inc) < age, 0)) \
                     { \
                         tally_add(&cb->events[RT_EV_ABORT]); \
                         ns = PS_LAUNCH; \
@@ -1078,6 +1080,7 @@ rt_trace_pool_kernel(const PoolArgs a)
     const int lane = threadIdx.x;
     uint32_t* const rec = lds;                                              // NS records
     uint8_t* const sel = reinterpret_cast<uint8_t*>(rec + NS * kPoolRec);   // 64 selected slots
+    sel[lane] = 0;          // every entry is a slot number from the start: a round reads its entry whether it serves or not
 
     // photon IDs of this wave: wave_left IDs from wave_next on, a chunk taken from the device-wide cursor
     uint64_t wave_next = 0;
@@ -1104,18 +1107,42 @@ rt_trace_pool_kernel(const PoolArgs a)
              ev_abs = 0, ev_trans = 0;
     uint32_t rounds_t = 0, rounds_e = 0, lanes_t = 0, lanes_e = 0, rounds_x = 0, lanes_x = 0;
 
+    int th_launch = a.th_launch;          // held in a scalar register: reloaded from the kernel arguments at the top of
+    asm volatile("" : "+s"(th_launch));   // every round, its load would sit in front of the choice of the round's stage
     while (n_t + n_e + n_x + n_l > 0)
     {
         // serve the stage with the most photons waiting (ties: traverse, then event); launches
         // (regeneration) once th_launch slots are free or nothing else is left
         // (fullest first is the optimum: asking the dearer stages -- new direction, event -- to be 1/8 or 1/4 fuller
         // than the others before they are served, or less full, loses 0.4 .. 1.8 % on C4 and C3)
-        uint32_t cls = n_t >= n_e ? 0u : 1u;
-        cls = ((n_x >= RT_TH_SLAB) | (n_x > max(n_t, n_e))) ? 4u : cls;
-        cls = ((n_l >= a.th_launch) | (n_t + n_e + n_x == 0)) ? 3u : cls;
-        ++round_ctr;
-        const bool tick = (round_ctr & (kTickRounds - 1u)) == 0u;
-        const uint32_t age_inc = tick ? kAgeOne : 0u;
+        // (written out for the scalar unit: the compiler's own version of these three lines took a detour through a
+        // vector register and twenty scalar instructions, every round)
+        uint32_t cls;
+        {
+            const int mx = max(n_t, n_e), busy = n_t + n_e + n_x, th = th_launch;
+            asm("s_cmp_lt_i32 %[nt], %[ne]\n\t"
+                "s_cselect_b32 %[c], 1, 0\n\t"                 /* cls = n_t >= n_e ? 0 : 1 */
+                "s_cmp_gt_i32 %[nx], %[mx]\n\t"
+                "s_cselect_b32 %[c], 4, %[c]\n\t"
+                "s_cmp_ge_i32 %[nx], %[ts]\n\t"
+                "s_cselect_b32 %[c], 4, %[c]\n\t"              /* (n_x >= RT_TH_SLAB) | (n_x > max(n_t, n_e)) ? 4 */
+                "s_cmp_ge_i32 %[nl], %[th]\n\t"
+                "s_cselect_b32 %[c], 3, %[c]\n\t"
+                "s_cmp_eq_u32 %[busy], 0\n\t"
+                "s_cselect_b32 %[c], 3, %[c]"                   /* (n_l >= th_launch) | (nothing else waits) ? 3 */
+                : [c] "=&s"(cls)
+                : [nt] "s"(n_t), [ne] "s"(n_e), [nx] "s"(n_x), [mx] "s"(mx), [nl] "s"(n_l), [th] "s"(th), [busy] "s"(busy),
+                  [ts] "i"(RT_TH_SLAB)
+                : "scc");
+        }
+        // a tick of the step guard every kTickRounds-th round: the counter advances by 2^32 / kTickRounds and the
+        // carry out of the addition is the tick (two scalar instructions)
+        uint32_t age_inc;
+        asm("s_add_u32 %[c], %[c], %[step]\n\t"
+            "s_cselect_b32 %[inc], %[one], 0"
+            : [c] "+s"(round_ctr), [inc] "=s"(age_inc)
+            : [step] "i"((int)(0x100000000ull / kTickRounds)), [one] "i"((int)kAgeOne)
+            : "scc");
 
         // ---- gather up to 64 waiting slots into the lanes ----
         __builtin_amdgcn_s_setprio(RT_PRIO);
@@ -1129,15 +1156,16 @@ rt_trace_pool_kernel(const PoolArgs a)
             const bool match = (stv[h] >> 2) == cls;
             const unsigned long long m = __ballot(match);
             const int rank = found + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (match && rank < 64)
+            const bool taken = match && (h == 0 || rank < 64);      // (the first 64 slots always fit the 64 lanes)
+            if (taken)
                 sel[rank] = (uint8_t)sidx;
-            srv[h] = (match && rank < 64) ? rank : -1;
+            srv[h] = taken ? rank : -1;
             found += __popcll(m);
         }
         asm volatile("" ::: "memory");
         const int n = found < 64 ? found : 64;
         const bool active = lane < n;
-        const uint32_t slot = active ? sel[lane] : 0u;
+        const uint32_t slot = sel[lane];         // (a lane that serves nothing reads a stale slot number and touches nothing)
         // group-major layout: group g of slot s at 16-byte element g*NS + s, so lanes serving
         // ascending slots read ascending addresses (a slot-major record stride of 64 B would put
         // every lane on the same four banks)
@@ -1148,8 +1176,11 @@ rt_trace_pool_kernel(const PoolArgs a)
         uint32_t ns = PS_DONE;           // new state of the photon this lane serves
         uint32_t out_lo = 0u, out_hn = 0u;   // its new ID words (event and launch stages)
 
+        // (the served stage's count loses its n lanes here, where the stage is known, and every count gains its new
+        // arrivals at the end of the round: four conditional subtractions on the scalar unit less)
         if (cls == 0u)
         {
+            n_t -= n;
             if (STATS) { ++rounds_t; lanes_t += n; }
             if (active)
             {
@@ -1182,6 +1213,7 @@ rt_trace_pool_kernel(const PoolArgs a)
         }
         else if (cls == 1u)
         {
+            n_e -= n;
             const ArgPtr k = args_now();
             if (STATS) { ++rounds_e; lanes_e += n; }
             // the photon's ID words live in the registers of the lane that owns its slot
@@ -1329,6 +1361,7 @@ rt_trace_pool_kernel(const PoolArgs a)
         }
         else if (__builtin_expect(cls == 4u, 0))
         {
+            n_x -= n;
             const ArgPtr k = args_now();
             // ---- slab stage: everything outside the grid ----
             __builtin_amdgcn_s_setprio(0);
@@ -1355,6 +1388,7 @@ rt_trace_pool_kernel(const PoolArgs a)
         }
         else
         {
+            n_l -= n;
             const ArgPtr k = args_now();
             // ---- launch (regeneration), raytracer_kernels.cu:180-208: next IDs of this wave's range ----
             __builtin_amdgcn_s_setprio(0);
@@ -1532,8 +1566,7 @@ rt_trace_pool_kernel(const PoolArgs a)
         const uint32_t ncls = active ? (ns >> 2) : 5u;
         const int d_t = __popcll(__ballot(ncls == 0u)), d_e = __popcll(__ballot(ncls == 1u)),
                   d_l = __popcll(__ballot(ncls == 3u)), d_x = __popcll(__ballot(ncls == 4u));
-        n_t += d_t - (cls == 0u ? n : 0); n_e += d_e - (cls == 1u ? n : 0);
-        n_l += d_l - (cls == 3u ? n : 0); n_x += d_x - (cls == 4u ? n : 0);
+        n_t += d_t; n_e += d_e; n_l += d_l; n_x += d_x;
     }
 
     if (STATS)

@@ -15,7 +15,7 @@ s=mark(s,"        else if (cls == 2u)\n        {","S_BEGIN")
 s=mark(s,"        else if (__builtin_expect(cls == 4u, 0))\n        {","X_BEGIN")
 s=mark(s,"            RT_SLAB_TALLY(tally_word)\n        }\n        else\n        {","L_BEGIN")
 s=mark(s,"#undef R4\n#undef RW\n","END_STAGES")
-s=mark(s,"        ++round_ctr;","SELECT_BEGIN",after=False)
+s=mark(s,"        uint32_t age_inc;","SELECT_BEGIN",after=False)
 open('/tmp/isa/mark.hip','w').write(s)
 PY
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -DRT_ONLY_DEFAULT_POOL "$@" -S --cuda-device-only mark.hip -o mark.s 2>&1 | grep error
