@@ -1595,9 +1595,17 @@ rt_trace_pool_kernel(const PoolArgs a)
 // Majorant grid of the cloud slab: per supervoxel the max of k_tot over its cells, stored as {M, 1/M}
 // (generalises k_ext_null of raytracer_3d_io.cu:73-74 from the domain to supervoxels), and the sum and
 // number of its cells for the growth criterion of the boxes (rt_boxes_kernel).
+// What the boxes' growth reads of a supervoxel, in one 16-byte record (one load per visit of rt_boxes_kernel, where
+// three arrays cost three: the pre-pass is bound by the latency of those loads).
+struct __attribute__((aligned(16))) SuperVoxel
+{
+    float m;        // majorant: max of k_tot over the supervoxel's cells
+    int cnt;        // number of its cells
+    double sum;     // sum of k_tot over them, cells in (k, j, i) order
+};
+
 __global__ void __launch_bounds__(64)
-rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, double* __restrict__ ksum,
-                   int* __restrict__ kcnt, uint32_t ncoarse,
+rt_majorant_kernel(const float4* __restrict__ cells, SuperVoxel* __restrict__ sv, uint32_t ncoarse,
                    int itot, int jtot, uint32_t nbi, uint32_t nbij, int k_lo, int k_end,
                    int sx, int sy, int sz, int nci, int ncj)
 {
@@ -1622,9 +1630,9 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, d
                 sum += (double)v;
                 ++cnt;
             }
-    maj[e] = make_float2(m, 1.0f / m);
-    ksum[e] = sum;
-    kcnt[e] = cnt;
+    SuperVoxel r;
+    r.m = m; r.cnt = cnt; r.sum = sum;
+    sv[e] = r;
 }
 
 // Majorant regions over the supervoxel grid: every supervoxel gets a BOX OF ITS OWN -- the supervoxels
@@ -1643,11 +1651,27 @@ rt_majorant_kernel(const float4* __restrict__ cells, float2* __restrict__ maj, d
 // in (k, j, i) order, sums in double: the oracle's copy of this routine must decide identically.
 // out[e] = {M of the box, the six extents in 5 bits each: xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25}.
 __global__ void __launch_bounds__(64)
-rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum, const int* __restrict__ kcnt,
+rt_boxes_kernel(const SuperVoxel* __restrict__ sv,
                 float2* __restrict__ out, unsigned int* __restrict__ any_box, uint32_t ncoarse, int nci, int ncj, int nck,
                 float hx, float hy, float hz, float tau, int max_extent)
 {
-    const uint32_t e = blockIdx.x * 64u + threadIdx.x;
+    // Which supervoxel a thread takes (its result does not depend on it): a wave takes a tile of 8 x 8 supervoxels of
+    // one level -- neighbours grow similar boxes, so its lanes walk layers of similar size -- and the waves are dealt
+    // out so that every XCD (workgroups go to the XCDs in turn) works its way through a band of its own, tile by tile
+    // and level by level: what a tile's boxes read (a neighbourhood of at most 70 x 70 supervoxels over all levels,
+    // 16 bytes each) stays in that XCD's L2. Dealt out in table order, 64 consecutive supervoxels per wave and
+    // neighbouring waves on different XCDs, nearly every load went out to the Infinity Cache and the pre-pass was
+    // bound by that latency (379 ms on the LES scene's 512 x 512 x 20 supervoxels).
+    const uint32_t ntx = ((uint32_t)nci + 7u) / 8u, nty = ((uint32_t)ncj + 7u) / 8u, nblocks = ntx * nty * (uint32_t)nck;
+    const uint32_t per_xcd = gridDim.x / (uint32_t)kXcds;          // the grid is kXcds * ceil(nblocks / kXcds)
+    const uint32_t lb = (blockIdx.x % (uint32_t)kXcds) * per_xcd + blockIdx.x / (uint32_t)kXcds;
+    if (lb >= nblocks)
+        return;
+    const uint32_t tile = lb / (uint32_t)nck;
+    const int ti = (int)(tile % ntx) * 8 + (int)(threadIdx.x & 7u), tj = (int)(tile / ntx) * 8 + (int)(threadIdx.x >> 3);
+    if (ti >= nci || tj >= ncj)
+        return;
+    const uint32_t e = ((lb % (uint32_t)nck) * (uint32_t)ncj + (uint32_t)tj) * (uint32_t)nci + (uint32_t)ti;
     if (e >= ncoarse)
         return;
     const int dims[3] = {nci, ncj, nck};
@@ -1657,9 +1681,9 @@ rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum
     const int ci = b[0], cj = b[2], ck = b[4];
     const int c3[3] = {ci, cj, ck};
     b[1] = b[0] + 1; b[3] = b[2] + 1; b[5] = b[4] + 1;
-    float m = maj0[e].x;
-    double sum = ksum[e];
-    long long cnt = kcnt[e];
+    float m = sv[e].m;
+    double sum = sv[e].sum;
+    long long cnt = sv[e].cnt;
     int fails = 0, dir = 0;
     while (fails < 6)
     {
@@ -1680,10 +1704,10 @@ rt_boxes_kernel(const float2* __restrict__ maj0, const double* __restrict__ ksum
                     for (int ii = l[0]; ii < l[1]; ++ii)
                     {
                         const uint32_t q = (uint32_t)((kk * ncj + jj) * nci + ii);
-                        const float v = maj0[q].x;
-                        lm = v > lm ? v : lm;
-                        ls += ksum[q];
-                        lc += kcnt[q];
+                        const SuperVoxel r = sv[q];
+                        lm = r.m > lm ? r.m : lm;
+                        ls += r.sum;
+                        lc += r.cnt;
                     }
             const float nm = lm > m ? lm : m;
             const double nsum = sum + ls;
@@ -2313,32 +2337,29 @@ int build_majorants(rt_context* c)
     if (ncoarse)
     {
         // per supervoxel: majorant, sum and number of cells; then every supervoxel's box (rt_boxes_kernel)
-        float2* d_maj0 = nullptr;
-        double* d_ksum = nullptr;
-        int* d_kcnt = nullptr;
+        SuperVoxel* d_sv = nullptr;
         unsigned int* d_any = nullptr;
         unsigned int any = 0;
-        hipError_t e = hipMalloc(&d_maj0, sizeof(float2) * ncoarse);
-        if (e == hipSuccess) e = hipMalloc(&d_ksum, sizeof(double) * ncoarse);
-        if (e == hipSuccess) e = hipMalloc(&d_kcnt, sizeof(int) * ncoarse);
+        hipError_t e = hipMalloc(&d_sv, sizeof(SuperVoxel) * ncoarse);
         if (e == hipSuccess) e = hipMalloc(&d_any, sizeof(unsigned int));
         if (e == hipSuccess) e = hipMemsetAsync(d_any, 0, sizeof(unsigned int), c->stream);
         if (e == hipSuccess)
         {
             const dim3 grid((unsigned)((ncoarse + 63) / 64)), block(64);
             hipLaunchKernelGGL(rt_majorant_kernel, grid, block, 0, c->stream,
-                               c->d_cells, d_maj0, d_ksum, d_kcnt, (uint32_t)ncoarse, c->itot, c->jtot, c->nbi, c->nbij,
+                               c->d_cells, d_sv, (uint32_t)ncoarse, c->itot, c->jtot, c->nbi, c->nbij,
                                s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
-            hipLaunchKernelGGL(rt_boxes_kernel, grid, block, 0, c->stream, d_maj0, d_ksum, d_kcnt, c->d_maj, d_any,
+            // (a wave per tile of 8 x 8 supervoxels and level, the grid padded to a whole number per XCD)
+            const size_t btiles = (size_t)((s.nci + 7) / 8) * (size_t)((s.ncj + 7) / 8) * (size_t)s.nck;
+            const dim3 bgrid((unsigned)(((btiles + kXcds - 1) / kXcds) * kXcds));
+            hipLaunchKernelGGL(rt_boxes_kernel, bgrid, block, 0, c->stream, d_sv, c->d_maj, d_any,
                                (uint32_t)ncoarse, s.nci, s.ncj, s.nck, s.hx, s.hy, s.hz,
                                (float)((double)c->merge_tau_milli / 1000.0), 1 << levels);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&any, d_any, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (d_maj0) (void)hipFree(d_maj0);
-        if (d_ksum) (void)hipFree(d_ksum);
-        if (d_kcnt) (void)hipFree(d_kcnt);
+        if (d_sv) (void)hipFree(d_sv);
         if (d_any) (void)hipFree(d_any);
         RT_HIP(e);
         c->hier = any != 0;
