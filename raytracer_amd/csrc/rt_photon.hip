@@ -1650,6 +1650,11 @@ rt_majorant_kernel(const float4* __restrict__ cells, SuperVoxel* __restrict__ sv
 // slab): the optical depth of null collisions a crossing photon meets. One THREAD per supervoxel, the layer's cells
 // in (k, j, i) order, sums in double: the oracle's copy of this routine must decide identically.
 // out[e] = {M of the box, the six extents in 5 bits each: xm | xp << 5 | ym << 10 | yp << 15 | zm << 20 | zp << 25}.
+#ifndef RT_BOX_TILE_X
+#define RT_BOX_TILE_X 8
+#endif
+constexpr uint32_t kBoxTileX = RT_BOX_TILE_X, kBoxTileY = 64u / RT_BOX_TILE_X;      // a wave's tile of supervoxels
+
 __global__ void __launch_bounds__(64)
 rt_boxes_kernel(const SuperVoxel* __restrict__ sv,
                 float2* __restrict__ out, unsigned int* __restrict__ any_box, uint32_t ncoarse, int nci, int ncj, int nck,
@@ -1662,13 +1667,13 @@ rt_boxes_kernel(const SuperVoxel* __restrict__ sv,
     // 16 bytes each) stays in that XCD's L2. Dealt out in table order, 64 consecutive supervoxels per wave and
     // neighbouring waves on different XCDs, nearly every load went out to the Infinity Cache and the pre-pass was
     // bound by that latency (379 ms on the LES scene's 512 x 512 x 20 supervoxels).
-    const uint32_t ntx = ((uint32_t)nci + 7u) / 8u, nty = ((uint32_t)ncj + 7u) / 8u, nblocks = ntx * nty * (uint32_t)nck;
+    const uint32_t ntx = ((uint32_t)nci + kBoxTileX - 1u) / kBoxTileX, nty = ((uint32_t)ncj + kBoxTileY - 1u) / kBoxTileY, nblocks = ntx * nty * (uint32_t)nck;
     const uint32_t per_xcd = gridDim.x / (uint32_t)kXcds;          // the grid is kXcds * ceil(nblocks / kXcds)
     const uint32_t lb = (blockIdx.x % (uint32_t)kXcds) * per_xcd + blockIdx.x / (uint32_t)kXcds;
     if (lb >= nblocks)
         return;
     const uint32_t tile = lb / (uint32_t)nck;
-    const int ti = (int)(tile % ntx) * 8 + (int)(threadIdx.x & 7u), tj = (int)(tile / ntx) * 8 + (int)(threadIdx.x >> 3);
+    const int ti = (int)((tile % ntx) * kBoxTileX + (threadIdx.x % kBoxTileX)), tj = (int)((tile / ntx) * kBoxTileY + (threadIdx.x / kBoxTileX));
     if (ti >= nci || tj >= ncj)
         return;
     const uint32_t e = ((lb % (uint32_t)nck) * (uint32_t)ncj + (uint32_t)tj) * (uint32_t)nci + (uint32_t)ti;
@@ -2350,7 +2355,7 @@ int build_majorants(rt_context* c)
                                c->d_cells, d_sv, (uint32_t)ncoarse, c->itot, c->jtot, c->nbi, c->nbij,
                                s.k_lo, s.k_hi + 1, sgx, sgy, sgz, s.nci, s.ncj);
             // (a wave per tile of 8 x 8 supervoxels and level, the grid padded to a whole number per XCD)
-            const size_t btiles = (size_t)((s.nci + 7) / 8) * (size_t)((s.ncj + 7) / 8) * (size_t)s.nck;
+            const size_t btiles = (size_t)((s.nci + kBoxTileX - 1) / kBoxTileX) * (size_t)((s.ncj + kBoxTileY - 1) / kBoxTileY) * (size_t)s.nck;
             const dim3 bgrid((unsigned)(((btiles + kXcds - 1) / kXcds) * kXcds));
             hipLaunchKernelGGL(rt_boxes_kernel, bgrid, block, 0, c->stream, d_sv, c->d_maj, d_any,
                                (uint32_t)ncoarse, s.nci, s.ncj, s.nck, s.hx, s.hy, s.hz,
