@@ -749,7 +749,7 @@ rt_trace_kernel(const TraceArgs a)
 // (state >> 2 is the stage that serves it: 0 traverse, 1 event, 3 launch, 4 slab; class 2 was round 1's new-direction stage)
 // PS_LAUNCH_TALLY: a free slot whose last photon was absorbed in the air; word 0 of its record holds the tally word
 // that the next launch round adds to (see the event stage)
-enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_SURFACE = 5, PS_LAUNCH = 12, PS_LAUNCH_TALLY = 13, PS_SLAB = 16, PS_DONE = 20 };
+enum : uint32_t { PS_TRAVERSE = 0, PS_COLLIDE = 4, PS_LAUNCH = 12, PS_LAUNCH_TALLY = 13, PS_SLAB = 16, PS_SURFACE = 17, PS_DONE = 20 };
 enum : int { PHYS_COMPAT = 0, PHYS_FIXED_DOT = 1, PHYS_PLANAR = 2 };
 constexpr int kPoolRec = 12;
 constexpr uint32_t kAgeOne = 1u << 27, kAgeMask = 0xF8000000u;
@@ -1252,7 +1252,11 @@ rt_trace_pool_kernel(const PoolArgs a)
                 const float4 g1 = R4(1);
                 const float4 g2 = R4(2);
                 const uint32_t cicj = __float_as_uint(g1.w), cks = __float_as_uint(g2.w);
-                const bool on_surface = (cks >> 26) & 1u;          // surface event, not collision (set by the slab stage)
+                // (surface events -- the albedo test and the Lambert reflection -- belong to the slab stage since round 3: a
+                // photon that arrives at the surface has its event in the round of its arrival, and this stage, which is
+                // most of the kernel, lost their selects and the reflection's arithmetic: they ran here for one or two lanes
+                // in most rounds)
+                constexpr bool on_surface = false;
                 int ci = (int)(cicj & 0xffffu), cj = (int)(cicj >> 16), ck = (int)(cks & 0xffffu);
                 int slab = (int)((cks >> 16) & 0xffu);
                 uint32_t age = cks & kAgeMask;
@@ -1365,11 +1369,20 @@ rt_trace_pool_kernel(const PoolArgs a)
         {
             n_x -= n;
             const ArgPtr k = args_now();
-            // ---- slab stage: everything outside the grid ----
+            // ---- slab stage: everything outside the grid, and the surface event of a photon that arrives down there ----
             __builtin_amdgcn_s_setprio(0);
             if (STATS) { ++rounds_x; lanes_x += n; }
             const ColdPtr cb = cold_of_k(k);
             uint32_t tally_word = 0xffffffffu;
+            // the photon's ID words, for the Philox block of a surface event (registers of the lane that owns the slot)
+            uint32_t pid_lo = 0u, pn = 0u;
+#pragma unroll
+            for (int h = 0; h < kHalves; ++h)
+            {
+                const uint32_t lo = BPERM(slot & 63u, id_lo[h]), hn = BPERM(slot & 63u, id_hn[h]);
+                if ((slot >> 6) == (uint32_t)h) { pid_lo = lo; pn = hn; }
+            }
+            out_hn = pn;
             if (active)
             {
                 const float4 g0 = R4(0);
@@ -1380,11 +1393,50 @@ rt_trace_pool_kernel(const PoolArgs a)
                 int slab = (int)(int8_t)((cks >> 16) & 0xffu);
                 const bool up = iz > 0.0f;
                 uint32_t cicj = 0u, ck = cks & 0xffffu, age = cks & kAgeMask;
-                RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
-                R4(0) = make_float4(x, y, z, tau);
-                if (ns == PS_TRAVERSE)
+                uint32_t diffuse_bit = cks & (1u << 24);
+                // (bit 26: the photon reached the surface in the fused first step of its launch round, which has
+                // counted its arrival; its event is still to come)
+                if ((cks >> 26) & 1u)
+                    ns = PS_SURFACE;
+                else
+                {
+                    RT_SLAB_STEP(g1.x, g1.y, g1.z, iz, (cks >> 24) & 1u)
+                }
+                if (ns == PS_SURFACE)
+                {
+                    // the surface (raytracer_kernels.cu:463-486): reflected with probability albedo into a Lambertian
+                    // direction (one Philox block: w0 the test, w1 and w2 cosine and azimuth; tau is kept), else the photon ends
+                    const uint32_t pid_hi = pn & 0xffu;
+                    uint32_t nev = pn >> 8;
+                    uint32_t sk0 = key0, sk1 = key1;
+                    asm volatile("" : "+s"(sk0), "+s"(sk1));
+                    const u32x4 w = philox4x32_10(pid_lo, pid_hi, nev, 0u, sk0, sk1);
+                    ++nev;
+                    out_hn = pid_hi | (nev << 8);
+                    const bool worn = nev >= 0xffffffu;             // (as in the event stage)
+                    if (__builtin_expect(worn, 0))
+                        tally_add(&cb->events[RT_EV_ABORT]);
+                    ns = PS_LAUNCH;
+                    if (u01(w.x) <= cb->albedo && !worn)
+                    {
+                        const int i = cell_of(x, k->inv_dx, k->itot), j = cell_of(y, k->inv_dy, k->jtot);
+                        tally_add(&k->tallies[4u * k->ncol + (uint32_t)i + (uint32_t)j * (uint32_t)k->itot]);
+                        float ux = g1.x, uy = g1.y, uz = g1.z;
+                        RT_NEW_DIRECTION(true, false, 0.0f, u01(w.y), u01(w.z))
+                        diffuse_bit = 1u << 24;
+                        // upwards from the surface: through clear air, or -- where the grid reaches down to the ground -- back
+                        // into the supervoxel it came out of (its indices are still in the record: the oracle keeps them too)
+                        ns = slab == k->gslab ? PS_TRAVERSE : PS_SLAB;
+                        R4(1) = make_float4(ux, uy, uz, g1.w);
+                        RW(8) = __float_as_uint(dir_reciprocal(ux));
+                        RW(9) = __float_as_uint(dir_reciprocal(uy));
+                        RW(10) = __float_as_uint(dir_reciprocal(uz));
+                    }
+                }
+                else if (ns == PS_TRAVERSE)
                     RW(7) = cicj;
-                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | (cks & (1u << 24)) | (ns == PS_SURFACE ? 1u << 26 : 0u) | age;
+                R4(0) = make_float4(x, y, z, tau);
+                RW(11) = ck | (((uint32_t)slab & 0xffu) << 16) | diffuse_bit | age;
             }
             RT_SLAB_TALLY(tally_word)
         }
@@ -1545,7 +1597,7 @@ rt_trace_pool_kernel(const PoolArgs a)
             const uint32_t v = BPERM((uint32_t)srv[h] & 63u, ns);
             if (srv[h] >= 0) stv[h] = v;
         }
-        if (cls == 1u || cls == 3u)
+        if (cls != 0u)
         {
 #pragma unroll
             for (int h = 0; h < kHalves; ++h)
